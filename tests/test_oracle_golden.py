@@ -1,0 +1,220 @@
+"""Pin the CPU oracle against fixtures captured from the imported reference
+(tools/capture_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Trace, load
+from oracle import encode as oenc
+from oracle import nets as onets
+from oracle import sampler as osamp
+
+RTOL = 1e-5   # north_star: "within 1e-5 relative in fp32"
+
+
+def close(a, b, rtol=RTOL, scale=None, what=''):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30) if scale is None else scale
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, '%s: max rel-to-scale err %.3e' % (what, err)
+
+
+def tt(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz'])
+def test_training_steps_match_reference(name):
+    tr = Trace(name)
+    assert tr.kinds == ['D', 'D', 'G', 'D', 'D', 'G']
+    first_d = tr.kinds.index('D')
+    first_g = tr.kinds.index('G')
+    dp = {k: tt(v) for k, v in tr.params(first_d, 'p_before').items()}
+    gp = {k: tt(v) for k, v in tr.params(first_g, 'p_before').items()}
+    bn = {}
+    for l, w in enumerate(tr.gen_dim):
+        bn['seq.%d.bn.running_mean' % l] = torch.zeros(w)
+        bn['seq.%d.bn.running_var' % l] = torch.ones(w)
+        bn['seq.%d.bn.num_batches_tracked' % l] = torch.zeros((), dtype=torch.int64)
+    sd, sg = {'t': 0, 'm': {}, 'v': {}}, {'t': 0, 'm': {}, 'v': {}}
+    B = tr.B
+    for s, kind in enumerate(tr.kinds):
+        z = tt(tr.get(s, 'normal'))
+        cond = tt(tr.get(s, 'cond'))
+        expn = tt(tr.exp_full(s))
+        masks = [[tt(m) for m in grp] for grp in tr.masks(s)]
+        if kind == 'D':
+            perm = tt(tr.get(s, 'shuffle').astype(np.int64))
+            real = tt(tr.get(s, 'real').astype(np.float32))
+            alpha = tt(tr.get(s, 'rand').reshape(-1))
+            out = onets.d_step_grads(gp, dp, tr.span_info, tr.pac, z, cond, perm, real, expn,
+                                     masks[0], masks[1], masks[2], alpha, bn)
+            close(out['fake'], tr.get(s, 'fake'), what='fake')
+            close(out['fakeact'], tr.get(s, 'fakeact'), what='fakeact')
+            close(out['y_fake'], tr.get(s, 'd_out', 0), what='y_fake')
+            close(out['y_real'], tr.get(s, 'd_out', 1), what='y_real')
+            close(out['pen'], tr.get(s, 'pen'), what='pen')
+            close(out['pen'], tr.get(s, 'backward_value', 0), what='pen (backward)')
+            close(out['loss_d'], tr.get(s, 'backward_value', 1), what='loss_d')
+            grads = out['grads']
+            if tr.private:
+                # reference hook noise: (1/B)*sigma*randn scalar per hook firing (dp_cgan.py:643-647)
+                for per_bwd in tr.hook_noise(s):
+                    for pid, tot in per_bwd.items():
+                        k = tr.dkeys[pid]
+                        grads[k] = grads[k] + np.float32(tot / B)
+            ref_g = tr.params(s, 'g')
+            for k in tr.dkeys:
+                close(grads[k], ref_g[k], rtol=2e-5, what='D grad ' + k)
+            dp = onets.apply_update(dp, grads, sd)
+            ref_p = tr.params(s, 'p_after')          # recorded right after Adam, before the clamp
+            for k in tr.dkeys:
+                close(dp[k], ref_p[k], what='D param ' + k)
+            if tr.private:
+                dp = {k: v.clamp(-0.01, 0.01) for k, v in dp.items()}   # dp_cgan.py:657-661
+        else:
+            mask = tt(tr.get(s, 'mask'))
+            out = onets.g_step_grads(gp, dp, tr.span_info, tr.pac, z, cond, mask, expn, masks[0], bn)
+            close(out['fake'], tr.get(s, 'fake'), what='fake')
+            close(out['fakeact'], tr.get(s, 'fakeact'), what='fakeact')
+            close(out['ce'], tr.get(s, 'ce'), what='ce')
+            close(out['loss_g'], tr.get(s, 'backward_value', 0), what='loss_g')
+            ref_g = tr.params(s, 'g')
+            for k in tr.gkeys:
+                # a Linear bias in front of BatchNorm has an exactly-zero gradient; what autograd
+                # returns there is rounding noise, so judge it on the scale of its weight's gradient
+                sc = np.abs(ref_g[k.replace('fc.bias', 'fc.weight')]).max() if 'fc.bias' in k else None
+                close(out['grads'][k], ref_g[k], rtol=2e-5, scale=sc, what='G grad ' + k)
+            gp = onets.apply_update(gp, out['grads'], sg)
+            ref_p = tr.params(s, 'p_after')
+            for k in tr.gkeys:
+                # ... and Adam turns that rounding noise (|g| ~ 1e-10 << eps) into moves of up to
+                # lr per step, so those biases can only agree to a few lr in absolute terms
+                if 'fc.bias' in k:
+                    assert np.abs(gp[k].numpy() - ref_p[k]).max() < 2e-4 * sg['t']
+                else:
+                    close(gp[k], ref_p[k], what='G param ' + k)
+    # final state_dict, incl. BatchNorm running statistics (updated in D and G forwards, Q2)
+    for k, v in bn.items():
+        close(v, tr.z['gen_final/' + k], what=k)
+    for k in tr.gkeys:
+        if 'fc.bias' not in k:
+            close(gp[k], tr.z['gen_final/' + k], what='final ' + k)
+    for k in tr.dkeys:
+        close(dp[k], tr.z['disc_final/' + k], what='final ' + k)
+
+
+def test_cond_loss_closed_form_equals_loop():
+    tr = Trace('trace_np.npz')
+    s = tr.kinds.index('G')
+    fake = tt(tr.get(s, 'fake')).requires_grad_(True)
+    cond, mask = tt(tr.get(s, 'cond')), tt(tr.get(s, 'mask'))
+    a = onets.cond_loss_pair_loop(fake, cond, mask, tr.span_info)
+    (ga,) = torch.autograd.grad(a, fake)
+    b = onets.cond_loss_closed(fake, cond, mask, tr.span_info)
+    (gb,) = torch.autograd.grad(b, fake)
+    close(a.detach(), tr.get(s, 'ce'), what='loop vs reference')
+    close(b.detach(), a.detach(), what='closed vs loop')
+    close(gb, ga, what='closed grad vs loop grad')
+
+
+def test_gradient_penalty_analytic_equals_autograd():
+    tr = Trace('trace_np.npz')
+    s = tr.kinds.index('D')
+    dp = {k: tt(v).requires_grad_(True) for k, v in tr.params(s, 'p_before').items()}
+    torch.manual_seed(3)
+    n, K0 = tr.B // tr.pac, tr.pac * dp['seq.0.weight'].shape[1] // tr.pac
+    real = torch.randn(tr.B, K0 // tr.pac)
+    fake = torch.randn(tr.B, K0 // tr.pac, requires_grad=True)
+    alpha = torch.rand(n)
+    masks = [tt(m) for m in tr.masks(s)[2]]
+    pen = onets.gradient_penalty(dp, real, fake, tr.pac, alpha, masks)
+    keys = [k for k in dp if k.endswith('weight')]
+    ga = torch.autograd.grad(pen, [dp[k] for k in keys] + [fake], allow_unused=True)
+    assert ga[-1] is None or float(ga[-1].abs().max()) == 0.0      # d pen / d xhat == 0
+    # slopes at xhat
+    a = alpha.reshape(n, 1, 1).repeat(1, tr.pac, real.shape[1]).reshape(-1, real.shape[1])
+    h = (a * real + (1 - a) * fake).reshape(n, -1).detach()
+    slopes = []
+    idx = onets.disc_layers(dp)
+    for li, mk in zip(idx[:-1], masks):
+        pre = h @ dp['seq.%d.weight' % li].t() + dp['seq.%d.bias' % li]
+        sl = torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2)) * mk.float() * 2
+        slopes.append(sl.detach())
+        h = (pre * sl).detach()
+    pen2, g2 = onets.gradient_penalty_analytic({k: v.detach() for k, v in dp.items()}, tr.pac, slopes)
+    close(pen2, pen.detach(), what='pen')
+    for k, g in zip(keys, ga):
+        close(g2[k], g, what='gp grad ' + k)
+
+
+def test_sampler_tables_and_draws():
+    z = load('adult_sampler.npz')
+    tb = osamp.Tables(z['encoded'], z['span_info'])
+    assert np.array_equal(tb.pair_prob, z['pair_prob'])
+    assert np.array_equal(tb.pair_code, z['pair_cond_st'])
+    assert np.array_equal(tb.pair_n, z['pair_n_category'])
+    assert np.array_equal(tb.cond_st, z['column_cond_st'])
+    assert np.array_equal(tb.dims, z['column_n_category'])
+    pos = z['get_position']
+    for (a, b), v in zip(z['pair_id_keys'], z['pair_id_vals']):
+        i, j = int(np.where(pos == a)[0][0]), int(np.where(pos == b)[0][0])
+        assert tb.pair_of[(i, j)] == v == tb.pair_index(i, j)
+    sizes = z['rid_pair_sizes']
+    for p, lists in enumerate(tb.pair_rows):
+        assert [len(x) for x in lists] == [int(v) for v in sizes[p][:len(lists)]]
+    cond, mask, pid, vid = osamp.sample_condvec_pair(tb, z['call/pairs'], z['call/r'])
+    assert np.array_equal(cond, z['call/cond']) and cond.dtype == np.float32
+    assert np.array_equal(mask, z['call/mask']) and mask.dtype == np.int32
+    assert np.array_equal(pid, z['call/pair_id'])
+    assert np.array_equal(vid, z['call/val_idx'])
+    perm = z['call/perm']
+    k = osamp.rank_of_row(tb, pid[perm], vid[perm], z['call/row_ids'])
+    idx, rows = osamp.sample_data_pair(tb, pid[perm], vid[perm], k)
+    assert np.array_equal(idx, z['call/row_ids'])
+    assert np.array_equal(rows, z['call/real'])
+
+
+def test_sampler_draws_inside_training_trace():
+    """Every recorded sample_condvec_pair call in the training trace: two ones per row, and the
+    mask columns are exactly the two drawn columns."""
+    tr = Trace('trace_priv.npz')
+    for s in range(tr.n_steps):
+        cond, mask = tr.get(s, 'cond'), tr.get(s, 'mask')
+        assert (mask.sum(1) == 2).all() and (cond.sum(1) == 2).all()
+        pairs = np.stack([tr.get(s, 'choice', j) for j in range(tr.B)])
+        assert (np.sort(pairs, 1) == np.nonzero(mask)[1].reshape(tr.B, 2)).all()
+
+
+def test_encode_matches_reference():
+    z = load('adult_encode.npz')
+    table, enc, span = z['table'], z['encoded'], z['span_info']
+    us = z['choice_u'].reshape(len(z['continuous_columns']), -1)
+    outs = z['choice_out'].reshape(len(z['continuous_columns']), -1)
+    col_st = {}
+    st, ci, si = 0, 0, 0
+    span_l = span.tolist()
+    while si < len(span_l):
+        ncol = span_l[si][2]
+        col_st[ci] = st
+        st += sum(span_l[si + t][0] for t in range(ncol))
+        si += ncol
+        ci += 1
+    for j, ci in enumerate(z['continuous_columns'].tolist()):
+        g = lambda k: z['gm%d/%s' % (ci, k)]
+        A = oenc.gm_constants(g('weight_concentration_a'), g('weight_concentration_b'),
+                              g('mean_precision'), g('degrees_of_freedom'), g('precisions_cholesky'))
+        proba = oenc.predict_proba(table[:, ci], g('means'), g('precisions_cholesky'), A)
+        np.testing.assert_allclose(proba, g('predict_proba'), rtol=1e-12, atol=1e-300)
+        val, comp, onehot = oenc.transform_continuous(table[:, ci], g('means'), g('covariances'),
+                                                      g('valid'), g('predict_proba'), us[j])
+        assert np.array_equal(comp, outs[j])
+        nv = int(g('valid').sum())
+        st = col_st[ci]
+        assert np.array_equal(val, enc[:, st])
+        assert np.array_equal(onehot, enc[:, st + 1:st + 1 + nv])
+        # with the oracle's own closed-form responsibilities the picks are the same too
+        _, comp2, _ = oenc.transform_continuous(table[:, ci], g('means'), g('covariances'),
+                                                g('valid'), proba, us[j])
+        assert np.array_equal(comp2, comp)
