@@ -1,0 +1,167 @@
+// _apply_activate (tanh / Gumbel-softmax over the span table) forward + backward, and the
+// conditional cross-entropy loss (closed form) forward + gradient in one pass.
+// Reference: dp_cgan.py:280-327 (activation), :330-389 (cond loss, closed form per SURVEY F6).
+// All HBM-bound: 8 B per generator-output element for the activation, 4 B read (+4 written for
+// the gradient) per element plus the cond/mask rows for the loss.
+#include "dpc_common.h"
+
+// span table rows: (offset, dim, kind) kind 0 = tanh, 1 = gumbel-softmax
+__global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                           int64_t ldy, const int32_t* __restrict__ spans, int nspan,
+                                                           int64_t B, int Dd, const float* __restrict__ en, int64_t ld_en,
+                                                           const uint64_t* rng, uint32_t site, float inv_tau) {
+  int64_t total = B * nspan;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = idx / nspan;
+    int s = (int)(idx - b * nspan);
+    int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
+    const float* xr = x + b * ldx + off;
+    float* yr = y + b * ldy + off;
+    if (kind == 0) {
+      for (int j = 0; j < dim; ++j) yr[j] = tanhf(xr[j]);
+    } else {
+      float mx = -INFINITY;
+      for (int j = 0; j < dim; ++j) {
+        float e = en ? en[b * ld_en + off + j]
+                     : -logf(dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j))));
+        float t = (xr[j] - logf(e)) * inv_tau;
+        yr[j] = t;
+        mx = fmaxf(mx, t);
+      }
+      float sum = 0.f;
+      for (int j = 0; j < dim; ++j) {
+        float e = expf(yr[j] - mx);
+        yr[j] = e;
+        sum += e;
+      }
+      float inv = 1.f / sum;
+      for (int j = 0; j < dim; ++j) yr[j] *= inv;
+    }
+  }
+}
+
+extern "C" int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
+                                      int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
+                                      const uint64_t* rng, uint32_t site, float tau, void* stream) {
+  DPC_CHECK_ARG(x && y && spans, "apply_activate_fwd: null pointer");
+  DPC_CHECK_ARG(exp_noise || rng, "apply_activate_fwd: no noise source");
+  DPC_CHECK_ARG(B >= 0 && nspan >= 0 && ldx >= Dd && ldy >= Dd && tau > 0.f, "apply_activate_fwd: bad shape");
+  if (B == 0 || nspan == 0) return DPC_OK;
+  hipLaunchKernelGGL(activate_fwd_kernel, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// dx = dL/dx given y (saved activations) and dy.  tanh: dy (1 - y^2); softmax((x+g)/tau):
+// (1/tau) y (dy - sum_j y_j dy_j).  accumulate != 0 adds into dx.
+__global__ __launch_bounds__(256) void activate_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ dy, int64_t lddy,
+                                                           float* __restrict__ dx, int64_t lddx,
+                                                           const int32_t* __restrict__ spans, int nspan, int64_t B,
+                                                           float inv_tau, int accumulate) {
+  int64_t total = B * nspan;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = idx / nspan;
+    int s = (int)(idx - b * nspan);
+    int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
+    const float* yr = y + b * ldy + off;
+    const float* gr = dy + b * lddy + off;
+    float* dr = dx + b * lddx + off;
+    if (kind == 0) {
+      for (int j = 0; j < dim; ++j) {
+        float v = gr[j] * (1.f - yr[j] * yr[j]);
+        dr[j] = accumulate ? dr[j] + v : v;
+      }
+    } else {
+      float dot = 0.f;
+      for (int j = 0; j < dim; ++j) dot += yr[j] * gr[j];
+      for (int j = 0; j < dim; ++j) {
+        float v = inv_tau * yr[j] * (gr[j] - dot);
+        dr[j] = accumulate ? dr[j] + v : v;
+      }
+    }
+  }
+}
+
+extern "C" int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx,
+                                      int64_t lddx, const int32_t* spans, int nspan, int64_t B, float tau,
+                                      int accumulate, void* stream) {
+  DPC_CHECK_ARG(y && dy && dx && spans, "apply_activate_bwd: null pointer");
+  DPC_CHECK_ARG(B >= 0 && nspan >= 0 && tau > 0.f, "apply_activate_bwd: bad shape");
+  if (B == 0 || nspan == 0) return DPC_OK;
+  hipLaunchKernelGGL(activate_bwd_kernel, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                     dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Conditional loss.  col2d[j] = discrete-column index of generator-output column j (-1 if j is not
+// inside a discrete column), col2c[j] = matching column of the cond vector.
+//   loss = 2/(B*nd) * sum_b sum_j m[b,col2d[j]] * (max(x,0) - x c + log1p(exp(-|x|)))
+//   dfake[b,j] = 2/(B*nd) * m * (sigmoid(x) - c)     (0 where col2d[j] < 0)
+// Block partial sums go to `partials[gridDim.x]`; cond_loss_finish adds them in index order
+// (bit-reproducible) and scales.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cond_loss_kernel(const float* __restrict__ fake, int64_t ldf,
+                                                        const float* __restrict__ cond, int64_t ldc,
+                                                        const int32_t* __restrict__ mask, int64_t ldm,
+                                                        const int32_t* __restrict__ col2d,
+                                                        const int32_t* __restrict__ col2c, int64_t B, int Dd,
+                                                        float scale, float* __restrict__ dfake, int64_t lddf,
+                                                        int accumulate, double* __restrict__ partials) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  int64_t total = B * Dd;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = idx / Dd;
+    int j = (int)(idx - b * Dd);
+    int d = col2d[j];
+    float gval = 0.f;
+    if (d >= 0) {
+      float m = (float)mask[b * ldm + d];
+      if (m != 0.f) {
+        float x = fake[b * ldf + j];
+        float c = cond[b * ldc + col2c[j]];
+        float e = expf(-fabsf(x));
+        acc += (double)(m * (fmaxf(x, 0.f) - x * c + log1pf(e)));
+        float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        gval = scale * m * (sig - c);
+      }
+    }
+    if (dfake) {
+      float* dp = dfake + b * lddf + j;
+      *dp = accumulate ? *dp + gval : gval;
+    }
+  }
+  double tot = dpc_block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ partials, int n, double scale, float* out) {
+  __shared__ double red[16];
+  // fixed-order: each thread sums a strided slice, then the block tree; same grid -> same bits.
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+  double tot = dpc_block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = (float)(tot * scale);
+}
+
+extern "C" int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
+                             int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
+                             float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
+                             int n_partials, void* stream) {
+  DPC_CHECK_ARG(fake && cond && mask && col2d && col2c && loss_out && partials, "cond_loss: null pointer");
+  DPC_CHECK_ARG(B > 0 && Dd > 0 && nd > 0, "cond_loss: bad shape");
+  DPC_CHECK_ARG(n_partials >= 1, "cond_loss: workspace too small");
+  int grid = dpc_grid(B * Dd, 256);
+  if (grid > n_partials) grid = n_partials;
+  float scale = (float)(2.0 / ((double)B * (double)nd));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cond_loss_kernel, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d, col2c, B,
+                     Dd, scale, dfake, lddf, accumulate, partials);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B * (double)nd), loss_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

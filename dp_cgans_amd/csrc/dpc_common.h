@@ -1,0 +1,110 @@
+// Shared device/host helpers for the DP-CGAN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DPC_OK 0
+#define DPC_EINVAL (-1)   // bad argument (shape, alignment, null pointer)
+#define DPC_EHIP (-2)     // HIP runtime reported an error at launch
+
+extern "C" void dpc_set_error(const char* msg);
+
+#define DPC_CHECK_ARG(cond, msg)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      dpc_set_error(msg);                   \
+      return DPC_EINVAL;                    \
+    }                                       \
+  } while (0)
+
+#define DPC_LAUNCH_CHECK()                        \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) {                      \
+      dpc_set_error(hipGetErrorString(e__));      \
+      return DPC_EHIP;                            \
+    }                                             \
+  } while (0)
+
+static inline int64_t dpc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid size for grid-stride elementwise kernels: enough blocks to fill 256 CUs x 8, no more.
+static inline int dpc_grid(int64_t work_items, int block) {
+  int64_t g = dpc_cdiv(work_items, block);
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNG state: two uint64 in device memory {seed, step}.  Every kernel that draws reads them from
+// the device so that a captured hipGraph replays with fresh numbers; dpc_rng_advance bumps step.
+// Stream layout: Philox4x32-10, key = seed, counter = {idx/4 lo, idx/4 hi, step lo, site | step hi<<16};
+// draw number idx of (site, step) is lane idx%4 of that block.  dpc_fill_* expose the same
+// mapping, so the draws a fused kernel used can be reproduced and handed to the oracle.
+// ---------------------------------------------------------------------------------------------
+struct DpcPhilox4 {
+  uint32_t v[4];
+};
+
+__device__ __forceinline__ DpcPhilox4 dpc_philox(uint64_t seed, uint64_t step, uint32_t site, uint64_t blk) {
+  uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32);
+  uint32_t c2 = (uint32_t)step, c3 = (site & 0xffffu) | ((uint32_t)(step >> 32) << 16);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  DpcPhilox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+__device__ __forceinline__ uint32_t dpc_draw_u32(const uint64_t* rng, uint32_t site, uint64_t idx) {
+  DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 2);
+  return p.v[idx & 3];
+}
+
+// (0,1) open interval, 24 bits.
+__device__ __forceinline__ float dpc_u32_to_unit(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// [0,1) with 53 bits from two draws (matches the resolution of numpy's random_sample).
+__device__ __forceinline__ double dpc_u64_to_unit(uint32_t hi, uint32_t lo) {
+  uint64_t a = hi >> 5, b = lo >> 6;
+  return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+// Standard normal number idx of (site, step): Box-Muller on draws 2*idx, 2*idx+1.
+__device__ __forceinline__ float dpc_draw_normal(const uint64_t* rng, uint32_t site, uint64_t idx) {
+  DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 1);
+  int h = (int)(idx & 1) * 2;
+  float u1 = dpc_u32_to_unit(p.v[h]), u2 = dpc_u32_to_unit(p.v[h + 1]);
+  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / block reductions
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T dpc_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a block of up to 1024 threads; result valid in every thread.  smem: >= 16 elements.
+template <typename T>
+__device__ __forceinline__ T dpc_block_sum(T v, T* smem) {
+  v = dpc_wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  T t = (T)0;
+  for (int i = 0; i < nw; ++i) t += smem[i];
+  return t;
+}

@@ -1,0 +1,300 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+//   C[M,N] = epi( alpha * sum_k A(m,k) * B(k,n) + bias[n] ) (+ beta * C)
+//
+// A(m,k) and B(k,n) are addressed with two strides each, one of which must be 1; that covers the
+// three products the DP-CGAN step needs without any transposed copies:
+//   forward  y  = x W^T   A = x  (k contiguous)   B = W viewed (k, n) -> W[n,k]  (k contiguous)
+//   input    dx = dy W    A = dy (k contiguous)   B = W[k,n]                      (n contiguous)
+//   weight   dW = dy^T x  A = dy viewed (m, k) -> dy[k,m] (m contiguous)   B = x[k,n] (n contiguous)
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 or 64x64), BK = 16,
+// operands staged global -> registers -> LDS as [k][m|n] images (k-major so that the 32 lanes of an
+// MFMA operand read consecutive dwords: conflict-free ds_read_b32), two LDS buffers, next tile's
+// global loads issued before the current tile's MFMAs (one barrier per K-tile).  Split-K over
+// gridDim.y with fp32 atomics for the weight-gradient shapes (small MxN, K = batch).  Block ids
+// are remapped so that the blocks sharing an A row-panel run on one XCD (private L2).
+#include "dpc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define EPI_NONE 0
+#define EPI_LEAKY_DROPOUT 1
+#define EPI_MUL 2
+#define EPI_RELU 3
+
+struct GemmArgs {
+  const float* A; int64_t a_rs, a_cs;
+  const float* B; int64_t b_rs, b_cs;
+  float* C; int64_t ldc;
+  int M, N, K;
+  float alpha, beta;
+  const float* bias;
+  int epi;
+  float* aux_out; int64_t ld_aux_out;
+  const float* aux_in; int64_t ld_aux_in;
+  const uint8_t* keep; int64_t ld_keep;
+  const uint64_t* rng; uint32_t site;
+  float leak;
+  int splitk, kchunk;
+  int tiles_m, tiles_n;
+  int a_vec, b_vec;
+};
+
+constexpr int BK = 16;
+
+template <int BMN, bool KC>
+struct Stage {
+  // KC: operand is k-contiguous in global memory (stride_mn = leading dimension, stride_k = 1).
+  // !KC: operand is m/n-contiguous (stride_k = leading dimension).
+  static constexpr int PASSES = BMN / 64;
+  static constexpr int LD = BMN + (KC ? 2 : 4);
+  float4 r[PASSES];
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int mn0, int k0,
+                                       int MN, int Kend, bool vec) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KC) {
+        int row = mn0 + p * 64 + (t >> 2);
+        int k = k0 + 4 * (t & 3);
+        if (row < MN) {
+          const float* src = base + (int64_t)row * ld + k;
+          if (vec && k + 3 < Kend) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k < Kend) v.x = src[0];
+            if (k + 1 < Kend) v.y = src[1];
+            if (k + 2 < Kend) v.z = src[2];
+            if (k + 3 < Kend) v.w = src[3];
+          }
+        }
+      } else {
+        constexpr int TPR = BMN / 4;            // threads per k-row
+        constexpr int RPP = 256 / TPR;          // k-rows per pass
+        int krow = p * RPP + t / TPR;
+        int mn = mn0 + 4 * (t % TPR);
+        int k = k0 + krow;
+        if (k < Kend) {
+          const float* src = base + (int64_t)k * ld + mn;
+          if (vec && mn + 3 < MN) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (mn < MN) v.x = src[0];
+            if (mn + 1 < MN) v.y = src[1];
+            if (mn + 2 < MN) v.z = src[2];
+            if (mn + 3 < MN) v.w = src[3];
+          }
+        }
+      }
+      r[p] = v;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ s) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      if (KC) {
+        int row = p * 64 + (t >> 2);
+        int kq = 4 * (t & 3);
+        s[(kq + 0) * LD + row] = r[p].x;
+        s[(kq + 1) * LD + row] = r[p].y;
+        s[(kq + 2) * LD + row] = r[p].z;
+        s[(kq + 3) * LD + row] = r[p].w;
+      } else {
+        constexpr int TPR = BMN / 4;
+        constexpr int RPP = 256 / TPR;
+        int krow = p * RPP + t / TPR;
+        *reinterpret_cast<float4*>(&s[krow * LD + 4 * (t % TPR)]) = r[p];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  using SA = Stage<BM, A_KC>;
+  using SB = Stage<BN, B_KC>;
+  constexpr int LDA = SA::LD, LDB = SB::LD;
+  constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDA + 2 * BK * LDB];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA;
+
+  // XCD-aware remap (bijective for any grid size): ids congruent mod 8 share an XCD, give each
+  // XCD a contiguous run of tiles so neighbours along N reuse the same A panel from one L2.
+  int nwg = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  int tile_m = wg / g.tiles_n, tile_n = wg - tile_m * g.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int k_begin = blockIdx.y * g.kchunk;
+  int k_end = min(g.K, k_begin + g.kchunk);
+  if (k_begin >= k_end && blockIdx.y > 0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+  const int li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int64_t lda = A_KC ? g.a_rs : g.a_cs;
+  const int64_t ldb = B_KC ? g.b_cs : g.b_rs;
+  SA sa;
+  SB sb;
+  const int ntile = (k_end - k_begin + BK - 1) / BK;
+  if (ntile > 0) {
+    sa.load(g.A, lda, m0, k_begin, g.M, k_end, g.a_vec);
+    sb.load(g.B, ldb, n0, k_begin, g.N, k_end, g.b_vec);
+    sa.store(As);
+    sb.store(Bs);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntile) {
+      sa.load(g.A, lda, m0, k_begin + (t + 1) * BK, g.M, k_end, g.a_vec);
+      sb.load(g.B, ldb, n0, k_begin + (t + 1) * BK, g.N, k_end, g.b_vec);
+    }
+    const float* as = As + cur * BK * LDA;
+    const float* bs = Bs + cur * BK * LDB;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[(kk + lk) * LDA + wm0 + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lk) * LDB + wn0 + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < ntile) {
+      sa.store(As + (cur ^ 1) * BK * LDA);
+      sb.store(Bs + (cur ^ 1) * BK * LDB);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = (g.bias && blockIdx.y == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][e] + bv;
+        float* cp = g.C + (int64_t)row * g.ldc + col;
+        if (g.splitk > 1) {
+          atomicAdd(cp, v);
+          continue;
+        }
+        if (g.epi == EPI_LEAKY_DROPOUT) {
+          float keep;
+          if (g.keep) {
+            keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+          } else {
+            keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
+          }
+          float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
+          g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+          v *= slope;
+        } else if (g.epi == EPI_MUL) {
+          v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+        } else if (g.epi == EPI_RELU) {
+          v = fmaxf(v, 0.f);
+        }
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        *cp = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
+  dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(256);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+}
+
+extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                            const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                            const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
+                            const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
+                            const uint64_t* rng, uint32_t site, float leak, int splitk, void* stream) {
+  DPC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  if (M == 0 || N == 0) return DPC_OK;
+  DPC_CHECK_ARG(A && B && C, "gemm: null operand");
+  DPC_CHECK_ARG(a_rs == 1 || a_cs == 1, "gemm: A needs one unit stride");
+  DPC_CHECK_ARG(b_rs == 1 || b_cs == 1, "gemm: B needs one unit stride");
+  DPC_CHECK_ARG(ldc >= N, "gemm: ldc < N");
+  DPC_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_RELU, "gemm: unknown epilogue");
+  DPC_CHECK_ARG(epi != EPI_LEAKY_DROPOUT || (aux_out && (keep || rng)), "gemm: dropout epilogue needs slope output and a mask source");
+  DPC_CHECK_ARG(epi != EPI_MUL || aux_in, "gemm: multiply epilogue needs aux_in");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g;
+  g.A = A; g.a_rs = a_rs; g.a_cs = a_cs;
+  g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.alpha = alpha; g.beta = beta; g.bias = bias; g.epi = epi;
+  g.aux_out = aux_out; g.ld_aux_out = ld_aux_out; g.aux_in = aux_in; g.ld_aux_in = ld_aux_in;
+  g.keep = keep; g.ld_keep = ld_keep; g.rng = rng; g.site = site; g.leak = leak;
+  // k-contiguous when the k stride is 1 (ties, e.g. K == 1, go to the k-contiguous path)
+  bool a_kc = (a_cs == 1), b_kc = (b_rs == 1);
+  int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
+  g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+  g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  // Tile choice: 128x128 only when it still yields at least one block per CU.
+  int64_t big = dpc_cdiv(M, 128) * dpc_cdiv(N, 128);
+  bool use_big = big >= 256;
+  int bm = use_big ? 128 : 64;
+  g.tiles_m = (int)dpc_cdiv(M, bm);
+  g.tiles_n = (int)dpc_cdiv(N, bm);
+  int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
+  if (splitk <= 0) {
+    // auto: split only plain accumulating products with a long K and too few tiles to fill the chip
+    splitk = 1;
+    if (epi == EPI_NONE && (beta == 0.f || beta == 1.f) && blocks < 128 && K >= 1024) {
+      int64_t s = dpc_cdiv(256, blocks);
+      int64_t maxs = K / 256;
+      if (s > maxs) s = maxs;
+      if (s > 32) s = 32;
+      if (s >= 2) splitk = (int)s;
+    }
+  }
+  DPC_CHECK_ARG(splitk == 1 || (epi == EPI_NONE && (beta == 0.f || beta == 1.f)), "gemm: split-K needs a plain epilogue and beta in {0,1}");
+  g.splitk = splitk;
+  int ktiles = (int)dpc_cdiv(K, BK);
+  g.kchunk = (int)dpc_cdiv(ktiles, splitk) * BK;
+  if (K == 0) g.kchunk = BK;
+  if (splitk > 1 && beta == 0.f) {
+    hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+    if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
+    g.beta = 1.f;   // accumulate into the zeroed C
+  }
+  if (use_big) launch_tile<128, 128>(g, a_kc, b_kc, st);
+  else launch_tile<64, 64>(g, a_kc, b_kc, st);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

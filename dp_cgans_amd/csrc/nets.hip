@@ -1,0 +1,334 @@
+// Non-GEMM pieces of the generator / discriminator / gradient-penalty passes.
+// Reference: Residual (Linear+BatchNorm1d+ReLU) dp_cgan.py:71-83, Discriminator :31-68,
+// calc_gradient_penalty :46-64 (analytic form).  All HBM-bound elementwise / column or
+// row reductions; reductions accumulate in fp64 and are bit-reproducible (fixed partial layout,
+// fixed summation order, no atomics).
+#include "dpc_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over a [rows, F] matrix: grid (ceil(F/64), R), block 256 = 64 columns x 4 row
+// lanes.  part layout: [R][NOUT][F] doubles.
+//   MODE 0: sum x, sum x^2                       (BatchNorm forward statistics)
+//   MODE 1: sum w[r] x                           (bias gradients, weighted row sums)
+//   MODE 2: sum dyh, sum dyh * xhat              (BatchNorm backward; dyh = dy * (y > 0))
+// ---------------------------------------------------------------------------------------------
+struct ColArgs {
+  const float* x; int64_t ldx; int64_t rows; int F;
+  const float* w;                                   // MODE 1 row weights (nullable -> 1)
+  const float* y; int64_t ldy; const float* z; int64_t ldz; const float* mean; const float* invstd;  // MODE 2
+  double* part; int R;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(ColArgs a) {
+  constexpr int NOUT = (MODE == 1) ? 1 : 2;
+  __shared__ double red[NOUT][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + c;
+  const int64_t per = (a.rows + a.R - 1) / a.R;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(a.rows, r0 + per);
+  double s0 = 0.0, s1 = 0.0;
+  if (f < a.F) {
+    float mu = 0.f, is = 0.f;
+    if (MODE == 2) { mu = a.mean[f]; is = a.invstd[f]; }
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      float v = a.x[r * a.ldx + f];
+      if (MODE == 0) {
+        s0 += (double)v;
+        s1 += (double)v * (double)v;
+      } else if (MODE == 1) {
+        s0 += (double)(a.w ? a.w[r] * v : v);
+      } else {
+        float dyh = a.y[r * a.ldy + f] > 0.f ? v : 0.f;
+        float xh = (a.z[r * a.ldz + f] - mu) * is;
+        s0 += (double)dyh;
+        s1 += (double)dyh * (double)xh;
+      }
+    }
+  }
+  red[0][rl][c] = s0;
+  if (NOUT == 2) red[1][rl][c] = s1;
+  __syncthreads();
+  if (rl == 0 && f < a.F) {
+    double t0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    a.part[((int64_t)blockIdx.y * NOUT + 0) * a.F + f] = t0;
+    if (NOUT == 2) {
+      double t1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+      a.part[((int64_t)blockIdx.y * NOUT + 1) * a.F + f] = t1;
+    }
+  }
+}
+
+static int pick_R(int64_t rows, int F, int max_R) {
+  // enough row chunks to spread the reduction over the chip, at least 64 rows per chunk
+  int64_t colblocks = dpc_cdiv(F, 64);
+  int64_t R = dpc_cdiv(1024, colblocks);
+  int64_t cap = dpc_cdiv(rows, 64);
+  if (R > cap) R = cap;
+  if (R > max_R) R = max_R;
+  if (R < 1) R = 1;
+  return (int)R;
+}
+
+// part must hold R * nout * F doubles; returns R through *R_out (R <= max_R).
+extern "C" int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int64_t rows, int F, const float* w,
+                                     const float* y, int64_t ldy, const float* z, int64_t ldz, const float* mean,
+                                     const float* invstd, double* part, int max_R, int* R_out, void* stream) {
+  DPC_CHECK_ARG(x && part && R_out, "colreduce_partial: null pointer");
+  DPC_CHECK_ARG(mode >= 0 && mode <= 2, "colreduce_partial: unknown mode");
+  DPC_CHECK_ARG(rows > 0 && F > 0 && ldx >= F && max_R >= 1, "colreduce_partial: bad shape");
+  DPC_CHECK_ARG(mode != 2 || (y && z && mean && invstd), "colreduce_partial: BatchNorm backward needs y, z, mean, invstd");
+  ColArgs a;
+  a.x = x; a.ldx = ldx; a.rows = rows; a.F = F; a.w = w; a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz; a.mean = mean;
+  a.invstd = invstd; a.part = part; a.R = pick_R(rows, F, max_R);
+  *R_out = a.R;
+  dim3 grid((unsigned)dpc_cdiv(F, 64), a.R), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(colreduce_kernel<0>, grid, block, 0, st, a);
+  else if (mode == 1) hipLaunchKernelGGL(colreduce_kernel<1>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(colreduce_kernel<2>, grid, block, 0, st, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// Finish a column reduction.  kind 0: BatchNorm statistics -> mean, invstd (+ running stats);
+// kind 1: plain sums -> out0 (float), accumulate optional; kind 2: two sums -> out0, out1 (dbeta, dgamma).
+__global__ __launch_bounds__(256) void colreduce_finish_kernel(const double* __restrict__ part, int R, int nout, int F,
+                                                               int kind, double count, float eps, float momentum,
+                                                               float* out0, float* out1, float* run_mean,
+                                                               float* run_var, int accumulate) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < R; ++r) {
+    s0 += part[((int64_t)r * nout + 0) * F + f];
+    if (nout == 2) s1 += part[((int64_t)r * nout + 1) * F + f];
+  }
+  if (kind == 0) {
+    double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out0[f] = (float)mean;
+    out1[f] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[f] = (1.f - momentum) * run_mean[f] + momentum * (float)mean;
+      run_var[f] = (1.f - momentum) * run_var[f] + momentum * (float)unbiased;
+    }
+  } else {
+    out0[f] = accumulate ? out0[f] + (float)s0 : (float)s0;
+    if (nout == 2) out1[f] = accumulate ? out1[f] + (float)s1 : (float)s1;
+  }
+}
+
+extern "C" int dpc_colreduce_finish(const double* part, int R, int nout, int F, int kind, double count, float eps,
+                                    float momentum, float* out0, float* out1, float* run_mean, float* run_var,
+                                    int accumulate, void* stream) {
+  DPC_CHECK_ARG(part && out0, "colreduce_finish: null pointer");
+  DPC_CHECK_ARG(R >= 1 && (nout == 1 || nout == 2) && F > 0 && kind >= 0 && kind <= 2, "colreduce_finish: bad argument");
+  DPC_CHECK_ARG(nout == 1 || out1, "colreduce_finish: second output missing");
+  DPC_CHECK_ARG(kind != 0 || (nout == 2 && count > 0.0), "colreduce_finish: statistics need two sums and a count");
+  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     R, nout, F, kind, count, eps, momentum, out0, out1, run_mean, run_var, accumulate);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// y = relu(gamma * (z - mean) * invstd + beta)
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ y,
+                                                          int64_t ldy, int64_t B, int F, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta) {
+  int64_t total = B * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / F;
+    int f = (int)(i - r * F);
+    float v = (z[r * ldz + f] - mean[f]) * invstd[f] * gamma[f] + beta[f];
+    y[r * ldy + f] = fmaxf(v, 0.f);
+  }
+}
+
+extern "C" int dpc_bn_relu_fwd(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, void* stream) {
+  DPC_CHECK_ARG(z && y && mean && invstd && gamma && beta, "bn_relu_fwd: null pointer");
+  DPC_CHECK_ARG(B > 0 && F > 0 && ldz >= F && ldy >= F, "bn_relu_fwd: bad shape");
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(dpc_grid(B * F, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, y, ldy,
+                     B, F, mean, invstd, gamma, beta);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// dz = gamma * invstd * (dyh - dbeta/count - xhat * dgamma/count),  dyh = dy * (y > 0)
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                          const float* __restrict__ y, int64_t ldy,
+                                                          const float* __restrict__ z, int64_t ldz, int64_t B, int F,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ dbeta,
+                                                          const float* __restrict__ dgamma, float inv_count,
+                                                          float* __restrict__ dz, int64_t lddz) {
+  int64_t total = B * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / F;
+    int f = (int)(i - r * F);
+    float dyh = y[r * ldy + f] > 0.f ? dy[r * lddy + f] : 0.f;
+    float xh = (z[r * ldz + f] - mean[f]) * invstd[f];
+    dz[r * lddz + f] = gamma[f] * invstd[f] * (dyh - dbeta[f] * inv_count - xh * dgamma[f] * inv_count);
+  }
+}
+
+extern "C" int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z, int64_t ldz,
+                               int64_t B, int F, const float* mean, const float* invstd, const float* gamma,
+                               const float* dbeta, const float* dgamma, double count, float* dz, int64_t lddz,
+                               void* stream) {
+  DPC_CHECK_ARG(dy && y && z && mean && invstd && gamma && dbeta && dgamma && dz, "bn_relu_bwd: null pointer");
+  DPC_CHECK_ARG(B > 0 && F > 0 && count > 0.0, "bn_relu_bwd: bad shape");
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(dpc_grid(B * F, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y,
+                     ldy, z, ldz, B, F, mean, invstd, gamma, dbeta, dgamma, (float)(1.0 / count), dz, lddz);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Discriminator head: y[r] = h[r,:] . w + b.  One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disc_out_kernel(const float* __restrict__ h, int64_t ldh,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       int64_t rows, int d, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float acc = 0.f;
+  for (int j = lane; j < d; j += 64) acc += h[r * ldh + j] * w[j];
+  acc = dpc_wave_sum(acc);
+  if (lane == 0) y[r] = acc + b[0];
+}
+
+extern "C" int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,
+                                float* y, void* stream) {
+  DPC_CHECK_ARG(h && w && b && y && rows > 0 && d > 0, "disc_out_fwd: bad argument");
+  hipLaunchKernelGGL(disc_out_kernel, dim3((unsigned)dpc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, w, b,
+                     rows, d, y);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// Seed of the downward chain: delta[r,j] = rowscale[r] * w[j] * slope[r,j].
+// With rowscale = +1/n (fake rows), -1/n (real rows), 1 (penalty rows) one chain serves both the
+// first-order backward of loss_d and the input-gradient ("g") chain of the penalty.
+__global__ __launch_bounds__(256) void disc_seed_kernel(const float* __restrict__ rowscale, const float* __restrict__ w,
+                                                        const float* __restrict__ slope, int64_t lds, int64_t rows,
+                                                        int d, float* __restrict__ delta, int64_t ldd) {
+  int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / d;
+    int j = (int)(i - r * d);
+    delta[r * ldd + j] = rowscale[r] * w[j] * slope[r * lds + j];
+  }
+}
+
+extern "C" int dpc_disc_seed(const float* rowscale, const float* w, const float* slope, int64_t lds, int64_t rows, int d,
+                             float* delta, int64_t ldd, void* stream) {
+  DPC_CHECK_ARG(rowscale && w && slope && delta && rows > 0 && d > 0, "disc_seed: bad argument");
+  hipLaunchKernelGGL(disc_seed_kernel, dim3(dpc_grid(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, rowscale, w,
+                     slope, lds, rows, d, delta, ldd);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// xhat rows of the stacked discriminator input: out = a*real + (1-a)*fake with one a per pac group
+// (pac consecutive rows of length rowlen).  alpha_inj[g] or Philox draw g; alpha_out optional.
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                          float* __restrict__ out, int64_t n, int64_t group_len,
+                                                          const float* __restrict__ alpha_inj, const uint64_t* rng,
+                                                          uint32_t site, float* alpha_out) {
+  int64_t total = n * group_len;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g = i / group_len;
+    float a = alpha_inj ? alpha_inj[g] : dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)g));
+    out[i] = a * real[i] + (1.f - a) * fake[i];
+    if (alpha_out && i == g * group_len) alpha_out[g] = a;
+  }
+}
+
+extern "C" int dpc_interpolate(const float* real, const float* fake, float* out, int64_t n, int64_t group_len,
+                               const float* alpha_inj, const uint64_t* rng, uint32_t site, float* alpha_out,
+                               void* stream) {
+  DPC_CHECK_ARG(real && fake && out && n > 0 && group_len > 0, "interpolate: bad argument");
+  DPC_CHECK_ARG(alpha_inj || rng, "interpolate: no random source");
+  hipLaunchKernelGGL(interpolate_kernel, dim3(dpc_grid(n * group_len, 256)), dim3(256), 0, (hipStream_t)stream, real,
+                     fake, out, n, group_len, alpha_inj, rng, site, alpha_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// Gradient-penalty row pass, in place: g0[r,:] -> v0[r,:] = coef * (nrm-1)/nrm * g0[r,:],
+// coef = 2*lambda/n_total; pen_rows[r] = (nrm-1)^2; nrm_out[r] = nrm.  One block per row.
+__global__ __launch_bounds__(256) void gp_norm_kernel(float* __restrict__ g0, int64_t ld, int64_t n, int K0, float coef,
+                                                      double* __restrict__ pen_rows, float* __restrict__ nrm_out) {
+  __shared__ double red[16];
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    float* row = g0 + r * ld;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < K0; j += blockDim.x) {
+      float v = row[j];
+      acc += (double)v * (double)v;
+    }
+    double tot = dpc_block_sum(acc, red);
+    float nrm = (float)sqrt(tot);
+    float f = nrm > 0.f ? coef * (nrm - 1.f) / nrm : 0.f;
+    for (int j = threadIdx.x; j < K0; j += blockDim.x) row[j] *= f;
+    if (threadIdx.x == 0) {
+      pen_rows[r] = (double)(nrm - 1.f) * (double)(nrm - 1.f);
+      if (nrm_out) nrm_out[r] = nrm;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef, double* pen_rows, float* nrm_out,
+                           void* stream) {
+  DPC_CHECK_ARG(g0 && pen_rows && n > 0 && K0 > 0 && ld >= K0, "gp_norm: bad argument");
+  hipLaunchKernelGGL(gp_norm_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, g0, ld, n,
+                     K0, coef, pen_rows, nrm_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// out[0] = scale * sum(v[0:n]) (+ out[0] if accumulate); fixed order, one block.  v is fp64.
+__global__ void sum_f64_kernel(const double* __restrict__ v, int64_t n, double scale, float* out, int accumulate) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += v[i];
+  double tot = dpc_block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = (float)(tot * scale) + (accumulate ? out[0] : 0.f);
+}
+
+extern "C" int dpc_sum_f64(const double* v, int64_t n, double scale, float* out, int accumulate, void* stream) {
+  DPC_CHECK_ARG(v && out && n > 0, "sum_f64: bad argument");
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, n, scale, out, accumulate);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// out[0] = sa * mean(y[0:n]) + sb * mean(y[n:2n]) (second term skipped when sb == 0) (+ out[0]).
+__global__ void mean_pair_kernel(const float* __restrict__ y, int64_t n, float sa, float sb, float* out, int accumulate) {
+  __shared__ double red[16];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    a += (double)y[i];
+    if (sb != 0.f) b += (double)y[n + i];
+  }
+  double ta = dpc_block_sum(a, red);
+  double tb = dpc_block_sum(b, red);
+  if (threadIdx.x == 0) out[0] = (float)(sa * ta / (double)n + sb * tb / (double)n) + (accumulate ? out[0] : 0.f);
+}
+
+extern "C" int dpc_mean_pair(const float* y, int64_t n, float sa, float sb, float* out, int accumulate, void* stream) {
+  DPC_CHECK_ARG(y && out && n > 0, "mean_pair: bad argument");
+  hipLaunchKernelGGL(mean_pair_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y, n, sa, sb, out, accumulate);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

@@ -1,0 +1,401 @@
+// DataSampler on the device (reference: data_sampler.py:9-198 tables, :245-343 condvec pairs,
+// :382-396 real-row pick) and the mode-specific encode (data_transformer.py:102-150).
+//
+// The reference materialises, per column pair and joint value, the list of matching row ids
+// (O(n_pairs * N) memory: 75 GB at 1 M rows x 9453 pairs).  Here the tables are
+//   bitmaps[C][W]  one N-bit row set per category (C = length of the cond vector, W = ceil(N/64))
+//   cnt[C][C]      co-occurrence counts  cnt[a][b] = popcount(bitmaps[a] & bitmaps[b])
+// and everything else is derived on the fly: the joint-value probabilities of a pair are a
+// d1 x d2 block of cnt, walked in the order numpy's unique() gives the packed codes (descending
+// value of the first column, then of the second), and "the k-th matching row" is the k-th set bit
+// of the AND of two bitmaps (popcount select).  All integer work; HBM/L2-bound.
+#include "dpc_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// table construction
+// ---------------------------------------------------------------------------------------------
+// One wave per 64-row word; loops over the discrete columns' categories.  cat_col[a] = column of
+// the encoded matrix that holds category a.
+__global__ __launch_bounds__(256) void build_bitmaps_kernel(const float* __restrict__ table, int64_t ld, int64_t N,
+                                                            const int32_t* __restrict__ cat_col, int C,
+                                                            uint64_t* __restrict__ bitmaps, int64_t W) {
+  int lane = threadIdx.x & 63;
+  int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= W) return;
+  int64_t row = w * 64 + lane;
+  const float* rp = table + row * ld;
+  for (int a = 0; a < C; ++a) {
+    bool bit = (row < N) && (rp[cat_col[a]] != 0.f);
+    unsigned long long m = __ballot(bit);
+    if (lane == 0) bitmaps[(int64_t)a * W + w] = m;
+  }
+}
+
+extern "C" int dpc_build_bitmaps(const float* table, int64_t ld, int64_t N, const int32_t* cat_col, int C,
+                                 uint64_t* bitmaps, int64_t W, void* stream) {
+  DPC_CHECK_ARG(table && cat_col && bitmaps, "build_bitmaps: null pointer");
+  DPC_CHECK_ARG(N > 0 && C > 0 && W == (N + 63) / 64, "build_bitmaps: W must be ceil(N/64)");
+  hipLaunchKernelGGL(build_bitmaps_kernel, dim3((unsigned)dpc_cdiv(W, 4)), dim3(256), 0, (hipStream_t)stream, table,
+                     ld, N, cat_col, C, bitmaps, W);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// cnt[a][b] for one (a, b) per block.
+__global__ __launch_bounds__(256) void cooccurrence_kernel(const uint64_t* __restrict__ bitmaps, int64_t W, int C,
+                                                           int32_t* __restrict__ cnt) {
+  __shared__ long long red[16];
+  int64_t pair = blockIdx.x;
+  int a = (int)(pair / C), b = (int)(pair - (int64_t)a * C);
+  const uint64_t* pa = bitmaps + (int64_t)a * W;
+  const uint64_t* pb = bitmaps + (int64_t)b * W;
+  long long acc = 0;
+  for (int64_t w = threadIdx.x; w < W; w += blockDim.x) acc += __popcll(pa[w] & pb[w]);
+  long long tot = dpc_block_sum(acc, red);
+  if (threadIdx.x == 0) cnt[pair] = (int32_t)tot;
+}
+
+extern "C" int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, void* stream) {
+  DPC_CHECK_ARG(bitmaps && cnt && W > 0 && C > 0, "cooccurrence: bad argument");
+  DPC_CHECK_ARG((int64_t)C * C < 2147483647LL, "cooccurrence: C*C exceeds the grid limit");
+  hipLaunchKernelGGL(cooccurrence_kernel, dim3((unsigned)((int64_t)C * C)), dim3(256), 0, (hipStream_t)stream, bitmaps,
+                     W, C, cnt);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample_condvec_pair: one wave per sample.
+// ---------------------------------------------------------------------------------------------
+struct CondvecArgs {
+  const int32_t* cnt; const int32_t* cond_st; const int32_t* dims; int nd, C; int64_t N;
+  const int32_t* pairs_inj; const double* r_inj; const uint64_t* rng; uint32_t site; int64_t B;
+  float* cond0; int64_t ld0; float* cond1; int64_t ld1; float* cond2; int64_t ld2;
+  int32_t* mask; int64_t ldm; int64_t* pair_id; int64_t* val_idx; int32_t* sel; int64_t* gcount;
+};
+
+__global__ __launch_bounds__(256) void condvec_pair_kernel(CondvecArgs a) {
+  const int lane = threadIdx.x & 63;
+  int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  int ca = 0, cb = 0, lo = 0, hi = 0;
+  if (lane == 0) {
+    int i, j;
+    double r;
+    if (a.pairs_inj) {
+      i = a.pairs_inj[2 * b];
+      j = a.pairs_inj[2 * b + 1];
+    } else {
+      // ordered draw of two distinct columns (np.random.choice(nd, 2, replace=False) in distribution)
+      float u1 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b));
+      float u2 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 1));
+      i = min(a.nd - 1, (int)(u1 * a.nd));
+      j = min(a.nd - 2, (int)(u2 * (a.nd - 1)));
+      if (j >= i) ++j;
+    }
+    if (a.r_inj) r = a.r_inj[b];
+    else r = dpc_u64_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 2), dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 3));
+    lo = min(i, j);
+    hi = max(i, j);
+    const int ka = a.dims[lo], kb = a.dims[hi], sa = a.cond_st[lo], sb = a.cond_st[hi];
+    // walk the pair's joint values in ascending packed-code order = (va desc, vb desc); fp64
+    // running sum of count/N in that order, exactly as cumsum over counts/sum(counts) does
+    double cum = 0.0;
+    const double dn = (double)a.N;
+    int found = 0, idx = 0, fva = 0, fvb = 0, fcnt = 0, have_first = 0, sva = 0, svb = 0, sidx = 0, scnt = 0;
+    for (int va = ka - 1; va >= 0 && !found; --va) {
+      const int32_t* rowp = a.cnt + (int64_t)(sa + va) * a.C + sb;
+      for (int vb = kb - 1; vb >= 0; --vb) {
+        int c = rowp[vb];
+        if (c <= 0) continue;
+        if (!have_first) { have_first = 1; fva = va; fvb = vb; fcnt = c; }
+        cum += (double)c / dn;
+        if (cum > r) { found = 1; sva = va; svb = vb; sidx = idx; scnt = c; break; }
+        ++idx;
+      }
+    }
+    if (!found) { sva = fva; svb = fvb; sidx = 0; scnt = fcnt; }   // argmax of an all-False row is 0
+    ca = sa + sva;
+    cb = sb + svb;
+    a.pair_id[b] = (int64_t)lo * a.nd - (int64_t)lo * (lo + 1) / 2 + (hi - lo - 1);
+    a.val_idx[b] = sidx;
+    if (a.sel) { a.sel[2 * b] = ca; a.sel[2 * b + 1] = cb; }
+    if (a.gcount) a.gcount[b] = scnt;
+  }
+  ca = __shfl(ca, 0, 64); cb = __shfl(cb, 0, 64); lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
+  for (int c = lane; c < a.C; c += 64) {
+    float v = (c == ca || c == cb) ? 1.f : 0.f;
+    if (a.cond0) a.cond0[b * a.ld0 + c] = v;
+    if (a.cond1) a.cond1[b * a.ld1 + c] = v;
+    if (a.cond2) a.cond2[b * a.ld2 + c] = v;
+  }
+  if (a.mask)
+    for (int d = lane; d < a.nd; d += 64) a.mask[b * a.ldm + d] = (d == lo || d == hi) ? 1 : 0;
+}
+
+extern "C" int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const int32_t* dims, int nd, int C,
+                                       int64_t N, const int32_t* pairs_inj, const double* r_inj, const uint64_t* rng,
+                                       uint32_t site, int64_t B, float* cond0, int64_t ld0, float* cond1, int64_t ld1,
+                                       float* cond2, int64_t ld2, int32_t* mask, int64_t ldm, int64_t* pair_id,
+                                       int64_t* val_idx, int32_t* sel, int64_t* gcount, void* stream) {
+  DPC_CHECK_ARG(cnt && cond_st && dims && pair_id && val_idx, "condvec_pair_sample: null pointer");
+  DPC_CHECK_ARG(nd >= 2 && C >= 2 && N > 0 && B >= 0, "condvec_pair_sample: needs >= 2 discrete columns");
+  DPC_CHECK_ARG((pairs_inj && r_inj) || rng, "condvec_pair_sample: no random source");
+  if (B == 0) return DPC_OK;
+  CondvecArgs a;
+  a.cnt = cnt; a.cond_st = cond_st; a.dims = dims; a.nd = nd; a.C = C; a.N = N; a.pairs_inj = pairs_inj;
+  a.r_inj = r_inj; a.rng = rng; a.site = site; a.B = B; a.cond0 = cond0; a.ld0 = ld0; a.cond1 = cond1; a.ld1 = ld1;
+  a.cond2 = cond2; a.ld2 = ld2; a.mask = mask; a.ldm = ldm; a.pair_id = pair_id; a.val_idx = val_idx; a.sel = sel;
+  a.gcount = gcount;
+  hipLaunchKernelGGL(condvec_pair_kernel, dim3((unsigned)dpc_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample_data_pair: row_id[b] = k-th (0-based) set bit of bitmaps[ca] & bitmaps[cb], where
+// (ca, cb) = sel[src], src = perm ? perm[b] : b.  One block per request; tiles of 1024 words,
+// block-wide popcount scan, early exit once the running count passes k.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_select_kernel(const uint64_t* __restrict__ bitmaps, int64_t W,
+                                                         const int32_t* __restrict__ sel,
+                                                         const int64_t* __restrict__ gcount,
+                                                         const int64_t* __restrict__ perm,
+                                                         const int64_t* __restrict__ k_inj, const uint64_t* rng,
+                                                         uint32_t site, int64_t B, int64_t* __restrict__ row_id) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    int64_t src = perm ? perm[b] : b;
+    const uint64_t* pa = bitmaps + (int64_t)sel[2 * src] * W;
+    const uint64_t* pb = bitmaps + (int64_t)sel[2 * src + 1] * W;
+    int64_t cntg = gcount[src];
+    int64_t k;
+    if (k_inj) k = k_inj[b];
+    else {
+      double u = dpc_u64_to_unit(dpc_draw_u32(rng, site, 2 * (uint64_t)b), dpc_draw_u32(rng, site, 2 * (uint64_t)b + 1));
+      k = (int64_t)(u * (double)cntg);
+      if (k > cntg - 1) k = cntg - 1;
+    }
+    if (k < 0 || k >= cntg) {           // empty group or bad injected rank: defined result, no scan
+      if (threadIdx.x == 0) row_id[b] = -1;
+      continue;
+    }
+    int64_t base = 0;
+    for (int64_t t0 = 0; t0 < W; t0 += 1024) {
+      int64_t w0 = t0 + 4 * (int64_t)threadIdx.x;
+      uint64_t x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = (w0 + q < W) ? (pa[w0 + q] & pb[w0 + q]) : 0ull;
+      int c = __popcll(x[0]) + __popcll(x[1]) + __popcll(x[2]) + __popcll(x[3]);
+      int incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+      }
+      __syncthreads();
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int woff = 0, ttot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < wave) woff += wsum[q];
+        ttot += wsum[q];
+      }
+      int64_t excl = base + woff + incl - c;
+      if (k >= excl && k < excl + c) {
+        int kk = (int)(k - excl);
+        int q = 0;
+        while (kk >= __popcll(x[q])) { kk -= __popcll(x[q]); ++q; }
+        uint64_t wv = x[q];
+        for (int i = 0; i < kk; ++i) wv &= wv - 1;
+        row_id[b] = (w0 + q) * 64 + (__ffsll((long long)wv) - 1);
+      }
+      base += ttot;
+      if (base > k) break;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,
+                              const int64_t* perm, const int64_t* k_inj, const uint64_t* rng, uint32_t site, int64_t B,
+                              int64_t* row_id, void* stream) {
+  DPC_CHECK_ARG(bitmaps && sel && gcount && row_id, "row_select: null pointer");
+  DPC_CHECK_ARG(k_inj || rng, "row_select: no random source");
+  DPC_CHECK_ARG(W > 0 && B >= 0, "row_select: bad shape");
+  if (B == 0) return DPC_OK;
+  int grid = (int)(B < 8192 ? B : 8192);
+  hipLaunchKernelGGL(row_select_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bitmaps, W, sel, gcount, perm,
+                     k_inj, rng, site, B, row_id);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// out[b, 0:Dd] = table[row_id[b], 0:Dd]; optionally out[b, Dd + c] = 1 at the two categories of
+// request src = perm ? perm[b] : b (the cond vector that travels with the real row, c1[perm]).
+__global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict__ table, int64_t ld,
+                                                         const int64_t* __restrict__ row_id, int64_t B, int Dd,
+                                                         float* __restrict__ out, int64_t ldo,
+                                                         const int32_t* __restrict__ sel,
+                                                         const int64_t* __restrict__ perm, int C) {
+  const int lane = threadIdx.x & 63;
+  int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int64_t rid = row_id[b];
+  const float* src = table + rid * ld;
+  float* dst = out + b * ldo;
+  for (int j = lane; j < Dd; j += 64) dst[j] = rid >= 0 ? src[j] : 0.f;
+  if (sel) {
+    int64_t s = perm ? perm[b] : b;
+    int ca = sel[2 * s], cb = sel[2 * s + 1];
+    for (int c = lane; c < C; c += 64) dst[Dd + c] = (c == ca || c == cb) ? 1.f : 0.f;
+  }
+}
+
+extern "C" int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd, float* out,
+                              int64_t ldo, const int32_t* sel, const int64_t* perm, int C, void* stream) {
+  DPC_CHECK_ARG(table && row_id && out, "row_gather: null pointer");
+  DPC_CHECK_ARG(B >= 0 && Dd > 0 && ld >= Dd && ldo >= Dd + (sel ? C : 0), "row_gather: bad shape");
+  if (B == 0) return DPC_OK;
+  hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)dpc_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, table, ld,
+                     row_id, B, Dd, out, ldo, sel, perm, C);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// Uniform random permutation of 0..B-1 by ranking 64-bit Philox keys (ties broken by index).
+__global__ __launch_bounds__(256) void perm_keys_kernel(const uint64_t* rng, uint32_t site, int64_t B, uint64_t* keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) keys[i] = ((uint64_t)dpc_draw_u32(rng, site, 2 * (uint64_t)i) << 32) | dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1);
+}
+__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* __restrict__ keys, int64_t B, int64_t* perm) {
+  __shared__ uint64_t tile[256];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t ki = i < B ? keys[i] : 0;
+  int64_t rank = 0;
+  for (int64_t t0 = 0; t0 < B; t0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = (t0 + threadIdx.x < B) ? keys[t0 + threadIdx.x] : ~0ull;
+    __syncthreads();
+    int lim = (int)min((int64_t)256, B - t0);
+    for (int j = 0; j < lim; ++j) {
+      uint64_t kj = tile[j];
+      rank += (kj < ki) || (kj == ki && (t0 + j) < i);
+    }
+  }
+  if (i < B) perm[rank] = i;
+}
+
+extern "C" int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
+                               void* stream) {
+  DPC_CHECK_ARG(rng && perm && keys_ws && B >= 0, "random_perm: bad argument");
+  if (B == 0) return DPC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned grid = (unsigned)dpc_cdiv(B, 256);
+  hipLaunchKernelGGL(perm_keys_kernel, dim3(grid), dim3(256), 0, st, rng, site, B, keys_ws);
+  hipLaunchKernelGGL(perm_rank_kernel, dim3(grid), dim3(256), 0, st, keys_ws, B, perm);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode (DataTransformer.transform)
+// ---------------------------------------------------------------------------------------------
+// Continuous column: tab = [mu(K) | sigma(K) | pc(K) | A(K)] (fp64), valid_idx = indices of the
+// kept mixture components.  Writes value at column col_off and the one-hot at col_off+1.. .
+#define DPC_MAX_COMP 16
+__global__ __launch_bounds__(256) void encode_continuous_kernel(const double* __restrict__ x, int64_t xs, int64_t N,
+                                                                const double* __restrict__ tab, int K,
+                                                                const int32_t* __restrict__ valid_idx, int nv,
+                                                                const double* __restrict__ u_inj, const uint64_t* rng,
+                                                                uint32_t site, double* out64, float* out32,
+                                                                int64_t ldo, int col_off, int32_t* comp_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double* mu = tab;
+  const double* sg = tab + K;
+  const double* pc = tab + 2 * K;
+  const double* A = tab + 3 * K;
+  double xv = x[i * xs];
+  double wlp[DPC_MAX_COMP];
+  double mx = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    double y = (xv - mu[k]) * pc[k];
+    wlp[k] = A[k] - 0.5 * (y * y);
+    mx = fmax(mx, wlp[k]);
+  }
+  double se = 0.0;
+  for (int k = 0; k < K; ++k) se += exp(wlp[k] - mx);
+  double lse = mx + log(se);
+  double pt[DPC_MAX_COMP];
+  double ps = 0.0;
+  for (int v = 0; v < nv; ++v) {
+    pt[v] = exp(wlp[valid_idx[v]] - lse) + 1e-6;
+    ps += pt[v];
+  }
+  double cum = 0.0, cdf[DPC_MAX_COMP];
+  for (int v = 0; v < nv; ++v) {
+    cum += pt[v] / ps;
+    cdf[v] = cum;
+  }
+  double u = u_inj ? u_inj[i]
+                   : dpc_u64_to_unit(dpc_draw_u32(rng, site, 2 * (uint64_t)i), dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1));
+  int comp = 0;
+  for (int v = 0; v < nv; ++v) comp += (cdf[v] / cum <= u) ? 1 : 0;    // searchsorted(cdf/cdf[-1], u, 'right')
+  if (comp > nv - 1) comp = nv - 1;
+  int kc = valid_idx[comp];
+  double val = (xv - mu[kc]) / (4.0 * sg[kc]);
+  val = fmin(fmax(val, -0.99), 0.99);
+  if (out64) {
+    double* o = out64 + i * ldo + col_off;
+    o[0] = val;
+    for (int v = 0; v < nv; ++v) o[1 + v] = (v == comp) ? 1.0 : 0.0;
+  }
+  if (out32) {
+    float* o = out32 + i * ldo + col_off;
+    o[0] = (float)val;
+    for (int v = 0; v < nv; ++v) o[1 + v] = (v == comp) ? 1.f : 0.f;
+  }
+  if (comp_out) comp_out[i] = comp;
+}
+
+extern "C" int dpc_encode_continuous(const double* x, int64_t x_stride, int64_t N, const double* tab, int K,
+                                     const int32_t* valid_idx, int nv, const double* u_inj, const uint64_t* rng,
+                                     uint32_t site, double* out64, float* out32, int64_t ldo, int col_off,
+                                     int32_t* comp_out, void* stream) {
+  DPC_CHECK_ARG(x && tab && valid_idx, "encode_continuous: null pointer");
+  DPC_CHECK_ARG(K >= 1 && K <= DPC_MAX_COMP && nv >= 1 && nv <= K, "encode_continuous: 1 <= n_valid <= K <= 16");
+  DPC_CHECK_ARG(u_inj || rng, "encode_continuous: no random source");
+  DPC_CHECK_ARG(out64 || out32, "encode_continuous: no output");
+  DPC_CHECK_ARG(ldo >= col_off + 1 + nv, "encode_continuous: output row too short");
+  if (N <= 0) return N == 0 ? DPC_OK : DPC_EINVAL;
+  hipLaunchKernelGGL(encode_continuous_kernel, dim3((unsigned)dpc_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     x_stride, N, tab, K, valid_idx, nv, u_inj, rng, site, out64, out32, ldo, col_off, comp_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// Discrete column: codes[i] in [0, dim) or -1 (unseen -> all zeros, as OneHotEncoder does).
+__global__ __launch_bounds__(256) void encode_onehot_kernel(const int32_t* __restrict__ codes, int64_t N, int dim,
+                                                            double* out64, float* out32, int64_t ldo, int col_off) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * dim) return;
+  int64_t i = idx / dim;
+  int j = (int)(idx - i * dim);
+  float v = (codes[i] == j) ? 1.f : 0.f;
+  if (out64) out64[i * ldo + col_off + j] = v;
+  if (out32) out32[i * ldo + col_off + j] = v;
+}
+
+extern "C" int dpc_encode_onehot(const int32_t* codes, int64_t N, int dim, double* out64, float* out32, int64_t ldo,
+                                 int col_off, void* stream) {
+  DPC_CHECK_ARG(codes && (out64 || out32), "encode_onehot: null pointer");
+  DPC_CHECK_ARG(dim >= 1 && ldo >= col_off + dim, "encode_onehot: bad shape");
+  if (N <= 0) return N == 0 ? DPC_OK : DPC_EINVAL;
+  hipLaunchKernelGGL(encode_onehot_kernel, dim3((unsigned)dpc_cdiv(N * dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                     codes, N, dim, out64, out32, ldo, col_off);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

@@ -1,0 +1,238 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/dpcgan_hip.h).
+
+Tensors are only used for device memory and the current HIP stream; every computation below runs
+in libdpcgan_hip.so.  All functions launch asynchronously on ``torch.cuda.current_stream()``.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib
+
+EPI_NONE, EPI_LEAKY_DROPOUT, EPI_MUL, EPI_RELU = 0, 1, 2, 3
+FILL_U32, FILL_NORMAL, FILL_EXP, FILL_UNIFORM, FILL_UNIFORM64, FILL_KEEP = 0, 1, 2, 3, 4, 5
+
+# call-site ids of the Philox streams (one independent stream per site and step)
+SITE_Z, SITE_GUMBEL, SITE_DROP0, SITE_ALPHA, SITE_CONDVEC, SITE_ROWPICK, SITE_PERM = 1, 2, 16, 3, 4, 5, 6
+SITE_NOISE_D, SITE_HOOK, SITE_ENCODE = 7, 8, 9
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError('%s must live on the GPU' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+
+
+def _ld(t):
+    """Leading dimension of a 2-D row-major view (unit stride along columns required)."""
+    if t.dim() == 1:
+        return t.shape[0]
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError('expected a 2-D tensor with unit column stride, got strides %s' % (t.stride(),))
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def new_rng(seed, device):
+    """Device-resident {seed, step} pair."""
+    return torch.tensor([seed & 0x7fffffffffffffff, 0], dtype=torch.int64, device=device)
+
+
+def state_advance(rng=None, t_a=None, t_b=None):
+    lib().call('dpc_state_advance', _p(rng), _p(t_a), _p(t_b), _stream())
+
+
+def fill(out, kind, rng, site, a=0.0, b=1.0):
+    """out (2-D view or 1-D) <- Philox draws of (site, step); element (r, c) uses draw r*cols + c."""
+    o2 = out if out.dim() == 2 else out.view(1, -1)
+    lib().call('dpc_fill', _p(o2), kind, _ld(o2), o2.shape[0], o2.shape[1], _p(rng), site, a, b, _stream())
+    return out
+
+
+def _mat_strides(t, trans):
+    """(row stride, col stride) of op(t) where t is a 2-D view with one unit stride."""
+    rs, cs = t.stride(0), t.stride(1)
+    if t.shape[0] == 1 and cs == 1:
+        rs = max(rs, t.shape[1])
+    if t.shape[1] == 1 and rs == 1:
+        cs = max(cs, t.shape[0])
+    return (cs, rs) if trans else (rs, cs)
+
+
+def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
+         aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=0):
+    """C = epi(alpha * op(A) @ op(B) + bias) + beta * C on the matrix cores (fp32 MFMA)."""
+    for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (aux_out, 'aux_out'), (aux_in, 'aux_in')):
+        _chk(t, torch.float32, n)
+    _chk(keep, torch.uint8, 'keep')
+    a_rs, a_cs = _mat_strides(A, trans_a)
+    b_rs, b_cs = _mat_strides(B, trans_b)
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2 or C.shape[0] != M or C.shape[1] != N:
+        raise ValueError('gemm shape mismatch: op(A) %dx%d, op(B) %dx%d, C %s' % (M, K, K2, N, tuple(C.shape)))
+    lib().call('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
+               epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
+               _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
+               site, leak, splitk, _stream())
+    return C
+
+
+def apply_activate_fwd(x, y, spans, exp_noise=None, rng=None, site=SITE_GUMBEL, tau=0.2):
+    B, Dd = x.shape
+    lib().call('dpc_apply_activate_fwd', _p(x), _ld(x), _p(y), _ld(y), _p(spans), spans.shape[0], B, Dd, _p(exp_noise),
+               _ld(exp_noise) if exp_noise is not None else 0, _p(rng), site, tau, _stream())
+    return y
+
+
+def apply_activate_bwd(y, dy, dx, spans, tau=0.2, accumulate=False):
+    lib().call('dpc_apply_activate_bwd', _p(y), _ld(y), _p(dy), _ld(dy), _p(dx), _ld(dx), _p(spans), spans.shape[0],
+               dx.shape[0], tau, int(accumulate), _stream())
+    return dx
+
+
+def cond_loss(fake, cond, mask, col2d, col2c, nd, loss_out, dfake, partials, accumulate=False):
+    _chk(mask, torch.int32, 'mask')
+    _chk(partials, torch.float64, 'partials')
+    B, Dd = fake.shape
+    lib().call('dpc_cond_loss', _p(fake), _ld(fake), _p(cond), _ld(cond), _p(mask), _ld(mask), _p(col2d), _p(col2c), B,
+               Dd, nd, _p(loss_out), _p(dfake), _ld(dfake) if dfake is not None else 0, int(accumulate), _p(partials),
+               partials.numel(), _stream())
+    return loss_out
+
+
+def build_bitmaps(table, cat_col, bitmaps):
+    N = table.shape[0]
+    C, W = bitmaps.shape
+    lib().call('dpc_build_bitmaps', _p(table), _ld(table), N, _p(cat_col), C, _p(bitmaps), W, _stream())
+    return bitmaps
+
+
+def cooccurrence(bitmaps, cnt):
+    C, W = bitmaps.shape
+    lib().call('dpc_cooccurrence', _p(bitmaps), W, C, _p(cnt), _stream())
+    return cnt
+
+
+def condvec_pair_sample(cnt, cond_st, dims, N, B, cond_dsts, mask, pair_id, val_idx, sel=None, gcount=None,
+                        pairs_inj=None, r_inj=None, rng=None, site=SITE_CONDVEC):
+    _chk(pairs_inj, torch.int32, 'pairs_inj')
+    _chk(r_inj, torch.float64, 'r_inj')
+    nd, C = dims.shape[0], cnt.shape[0]
+    d = list(cond_dsts) + [None] * (3 - len(cond_dsts))
+    args = []
+    for t in d:
+        args += [_p(t), _ld(t) if t is not None else 0]
+    lib().call('dpc_condvec_pair_sample', _p(cnt), _p(cond_st), _p(dims), nd, C, N, _p(pairs_inj), _p(r_inj), _p(rng),
+               site, B, *args, _p(mask), _ld(mask) if mask is not None else 0, _p(pair_id), _p(val_idx), _p(sel),
+               _p(gcount), _stream())
+
+
+def row_select(bitmaps, sel, gcount, row_id, perm=None, k_inj=None, rng=None, site=SITE_ROWPICK):
+    _chk(perm, torch.int64, 'perm')
+    _chk(k_inj, torch.int64, 'k_inj')
+    lib().call('dpc_row_select', _p(bitmaps), bitmaps.shape[1], _p(sel), _p(gcount), _p(perm), _p(k_inj), _p(rng), site,
+               row_id.shape[0], _p(row_id), _stream())
+    return row_id
+
+
+def row_gather(table, row_id, out, Dd, sel=None, perm=None, C=0):
+    lib().call('dpc_row_gather', _p(table), _ld(table), _p(row_id), row_id.shape[0], Dd, _p(out), _ld(out), _p(sel),
+               _p(perm), C, _stream())
+    return out
+
+
+def random_perm(rng, perm, keys_ws, site=SITE_PERM):
+    lib().call('dpc_random_perm', _p(rng), site, perm.shape[0], _p(perm), _p(keys_ws), _stream())
+    return perm
+
+
+def encode_continuous(x, tab, valid_idx, out64=None, out32=None, col_off=0, u_inj=None, rng=None, site=SITE_ENCODE,
+                      comp_out=None):
+    _chk(x, torch.float64, 'x')
+    _chk(tab, torch.float64, 'tab')
+    _chk(valid_idx, torch.int32, 'valid_idx')
+    out = out64 if out64 is not None else out32
+    lib().call('dpc_encode_continuous', _p(x), x.stride(0), x.shape[0], _p(tab), tab.shape[1], _p(valid_idx),
+               valid_idx.shape[0], _p(u_inj), _p(rng), site, _p(out64), _p(out32), _ld(out), col_off, _p(comp_out),
+               _stream())
+
+
+def encode_onehot(codes, dim, out64=None, out32=None, col_off=0):
+    _chk(codes, torch.int32, 'codes')
+    out = out64 if out64 is not None else out32
+    lib().call('dpc_encode_onehot', _p(codes), codes.shape[0], dim, _p(out64), _p(out32), _ld(out), col_off, _stream())
+
+
+def colreduce_partial(mode, x, part, w=None, y=None, z=None, mean=None, invstd=None, max_R=64):
+    R = ctypes.c_int(0)
+    rows, F = x.shape
+    lib().call('dpc_colreduce_partial', mode, _p(x), _ld(x), rows, F, _p(w), _p(y), _ld(y) if y is not None else 0,
+               _p(z), _ld(z) if z is not None else 0, _p(mean), _p(invstd), _p(part), max_R, ctypes.byref(R), _stream())
+    return R.value
+
+
+def colreduce_finish(part, R, nout, F, kind, out0, out1=None, count=1.0, eps=1e-5, momentum=0.1, run_mean=None,
+                     run_var=None, accumulate=False):
+    lib().call('dpc_colreduce_finish', _p(part), R, nout, F, kind, float(count), eps, momentum, _p(out0), _p(out1),
+               _p(run_mean), _p(run_var), int(accumulate), _stream())
+
+
+def bn_relu_fwd(z, y, mean, invstd, gamma, beta):
+    lib().call('dpc_bn_relu_fwd', _p(z), _ld(z), _p(y), _ld(y), z.shape[0], z.shape[1], _p(mean), _p(invstd), _p(gamma),
+               _p(beta), _stream())
+
+
+def bn_relu_bwd(dy, y, z, mean, invstd, gamma, dbeta, dgamma, count, dz):
+    lib().call('dpc_bn_relu_bwd', _p(dy), _ld(dy), _p(y), _ld(y), _p(z), _ld(z), z.shape[0], z.shape[1], _p(mean),
+               _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), float(count), _p(dz), _ld(dz), _stream())
+
+
+def disc_out_fwd(h, w, b, y):
+    lib().call('dpc_disc_out_fwd', _p(h), _ld(h), _p(w), _p(b), h.shape[0], h.shape[1], _p(y), _stream())
+
+
+def disc_seed(rowscale, w, slope, delta):
+    lib().call('dpc_disc_seed', _p(rowscale), _p(w), _p(slope), _ld(slope), slope.shape[0], slope.shape[1], _p(delta),
+               _ld(delta), _stream())
+
+
+def interpolate(real, fake, out, n, group_len, alpha_inj=None, rng=None, site=SITE_ALPHA, alpha_out=None):
+    lib().call('dpc_interpolate', _p(real), _p(fake), _p(out), n, group_len, _p(alpha_inj), _p(rng), site,
+               _p(alpha_out), _stream())
+
+
+def gp_norm(g0, coef, pen_rows, nrm_out=None):
+    lib().call('dpc_gp_norm', _p(g0), _ld(g0), g0.shape[0], g0.shape[1], coef, _p(pen_rows), _p(nrm_out), _stream())
+
+
+def sum_f64(v, scale, out, accumulate=False):
+    lib().call('dpc_sum_f64', _p(v), v.numel(), float(scale), _p(out), int(accumulate), _stream())
+
+
+def mean_pair(y, n, sa, sb, out, accumulate=False):
+    lib().call('dpc_mean_pair', _p(y), n, sa, sb, _p(out), int(accumulate), _stream())
+
+
+def adam_step(p, g, m, v, lr, wd, b1=0.5, b2=0.9, eps=1e-8, clamp=0.0, gscale=1.0, t_dev=None, t_host=1,
+              seg_off=None, seg_add=None, noise_scale=0.0, noise_inj=None, rng=None, site=SITE_NOISE_D):
+    nseg = seg_add.shape[0] if seg_add is not None else 0
+    lib().call('dpc_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, wd, clamp, gscale, _p(t_dev),
+               t_host, _p(seg_off), _p(seg_add), nseg, noise_scale, _p(noise_inj), _p(rng), site, _stream())
+
+
+def noise_add_clamp(x, scale, noise_inj=None, rng=None, site=SITE_NOISE_D, clamp=0.0):
+    lib().call('dpc_noise_add_clamp', _p(x), x.numel(), scale, _p(noise_inj), _p(rng), site, clamp, _stream())
+    return x

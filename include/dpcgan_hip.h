@@ -1,0 +1,174 @@
+/* C-ABI of libdpcgan_hip.so: the gfx950 kernels under the DP-CGAN training step.
+ *
+ * The reference (sunchang0124/dp_cgans) is pure Python and has no FFI; the boundary it offers is
+ * the Python class API.  These entry points are what a maintainer would bind with
+ * ctypes from the reference's own modules to replace the stock-PyTorch / NumPy code cited beside
+ * each one (paths relative to /root/reference/src/dp_cgans/synthesizers/).  INTEGRATION.md shows
+ * the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says host; the caller owns all buffers;
+ *    nothing here allocates, frees or synchronises;
+ *  - `stream` is a hipStream_t; launches are asynchronous on it;
+ *  - return 0 on success, DPC_EINVAL (-1) for a rejected argument, DPC_EHIP (-2) when the HIP
+ *    runtime refused the launch; dpc_last_error() (host, thread-local) holds the message;
+ *  - matrices are row-major fp32 with an explicit leading dimension (elements, not bytes);
+ *  - randomness: `rng` points at two device uint64 {seed, step}.  Draw number idx of call site
+ *    `site` is Philox4x32-10(key = seed, counter = {idx/4, step, site}) lane idx%4, so a captured
+ *    graph replays with fresh numbers once dpc_state_advance has bumped `step`.  Every kernel
+ *    that draws also accepts an injected tensor instead (non-null pointer wins); that is how the
+ *    parity tests feed the reference's recorded draws.  dpc_fill exposes the same idx -> draw map.
+ */
+#ifndef DPCGAN_HIP_H
+#define DPCGAN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPC_OK 0
+#define DPC_EINVAL (-1)
+#define DPC_EHIP (-2)
+
+int dpc_version(void);
+const char* dpc_last_error(void);
+
+/* ---- random state / fills -------------------------------------------------------------- */
+/* rng[1] += 1, *t_a += 1, *t_b += 1 (any may be NULL).  No reference counterpart: the reference
+ * uses the global torch / numpy generators (dp_cgan.py:581, data_sampler.py:211,269). */
+int dpc_state_advance(uint64_t* rng, int32_t* t_a, int32_t* t_b, void* stream);
+
+/* out[r*ld + c] = draw(r*cols + c).  kind: 0 u32, 1 normal(a, b) f32 (torch.normal,
+ * dp_cgan.py:581,673), 2 Exp(1) f32 (Tensor.exponential_ inside F.gumbel_softmax, :307),
+ * 3 uniform(0,1) f32 (torch.rand, :47), 4 uniform[0,1) f64 (np.random.rand, data_sampler.py:211),
+ * 5 keep bit u8 (Dropout(0.5), :40). */
+int dpc_fill(void* out, int kind, int64_t ld, int64_t rows, int64_t cols, const uint64_t* rng,
+             uint32_t site, float a, float b, void* stream);
+
+/* ---- fp32 GEMM on the matrix cores (replaces every Linear forward/backward: dp_cgan.py:40,43,
+ * 75,95 and their autograd) --------------------------------------------------------------- */
+/* C = epi(alpha * A.B + bias) + beta*C.  A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs];
+ * one stride of each must be 1.  epi: 0 none; 1 bias+LeakyReLU(leak)+Dropout(0.5): writes
+ * slope = (pre>0 ? 1 : leak)*keep*2 to aux_out and C = pre*slope (keep from `keep` u8 [M,N] or
+ * Philox idx m*N+n); 2 multiply by aux_in[m,n]; 3 ReLU.  splitk 0 = automatic (fp32 atomics,
+ * only for epi 0 and beta in {0,1}). */
+int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                 const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                 const float* bias, int epi, float* aux_out, int64_t ld_aux_out, const float* aux_in,
+                 int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep, const uint64_t* rng,
+                 uint32_t site, float leak, int splitk, void* stream);
+
+/* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
+/* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)
+ * from exp_noise[b*ld_noise + col] or Philox idx b*Dd + col. */
+int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
+                           int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
+                           const uint64_t* rng, uint32_t site, float tau, void* stream);
+/* autograd of the above: dx (+)= J^T dy given the saved output y. */
+int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx,
+                           int64_t lddx, const int32_t* spans, int nspan, int64_t B, float tau,
+                           int accumulate, void* stream);
+
+/* ---- conditional loss (DPCGANSynthesizer._cond_loss_pair, dp_cgan.py:330-389), closed form --- */
+/* loss_out[0] = 2/(B*nd) sum_b sum_j mask[b,col2d[j]] * BCEWithLogits(fake[b,j], cond[b,col2c[j]]);
+ * dfake (nullable) gets d loss / d fake (zero outside discrete columns).  partials: fp64 workspace
+ * of n_partials (>= 1, 2048 is enough) elements. */
+int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
+                  int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
+                  float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
+                  int n_partials, void* stream);
+
+/* ---- DataSampler (data_sampler.py) ---------------------------------------------------------- */
+/* Tables (replace DataSampler.__init__, data_sampler.py:9-198): bitmaps[C][W] row sets per
+ * category, cnt[C][C] co-occurrence counts.  cat_col[a] = encoded-matrix column of category a. */
+int dpc_build_bitmaps(const float* table, int64_t ld, int64_t N, const int32_t* cat_col, int C,
+                      uint64_t* bitmaps, int64_t W, void* stream);
+int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, void* stream);
+/* sample_condvec_pair (data_sampler.py:245-343).  pairs_inj int32 [B][2] = the ordered draw of
+ * np.random.choice(nd, 2, replace=False); r_inj fp64 [B] = np.random.rand(B).  Writes cond to up
+ * to three destinations, mask int32, pair_id / val_idx int64, and for the row pick: sel int32
+ * [B][2] (the two chosen category ids) and gcount int64 [B] (size of the joint-value group). */
+int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const int32_t* dims, int nd,
+                            int C, int64_t N, const int32_t* pairs_inj, const double* r_inj,
+                            const uint64_t* rng, uint32_t site, int64_t B, float* cond0, int64_t ld0,
+                            float* cond1, int64_t ld1, float* cond2, int64_t ld2, int32_t* mask,
+                            int64_t ldm, int64_t* pair_id, int64_t* val_idx, int32_t* sel,
+                            int64_t* gcount, void* stream);
+/* sample_data_pair (data_sampler.py:382-396): row_id[b] = k-th smallest row id whose two
+ * categories are sel[perm ? perm[b] : b]; k = k_inj[b] or floor(u * gcount).  -1 for an empty group. */
+int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,
+                   const int64_t* perm, const int64_t* k_inj, const uint64_t* rng, uint32_t site,
+                   int64_t B, int64_t* row_id, void* stream);
+/* self._data[idx] (data_sampler.py:396) + the cond vector that travels with it (c_pair_1[perm],
+ * dp_cgan.py:607) written behind the row when sel != NULL. */
+int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd,
+                   float* out, int64_t ldo, const int32_t* sel, const int64_t* perm, int C,
+                   void* stream);
+/* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution; keys_ws: B uint64. */
+int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
+                    void* stream);
+
+/* ---- DataTransformer.transform (data_transformer.py:102-150) -------------------------------- */
+/* tab fp64 [4][K] = mu, sigma, precision_cholesky, A (A = the x-independent part of sklearn's
+ * weighted log-probability, see oracle/encode.py).  u_inj fp64 [N] = the uniform behind
+ * np.random.choice(p=).  Writes value at col_off and the one-hot of the picked component after it. */
+int dpc_encode_continuous(const double* x, int64_t x_stride, int64_t N, const double* tab, int K,
+                          const int32_t* valid_idx, int nv, const double* u_inj, const uint64_t* rng,
+                          uint32_t site, double* out64, float* out32, int64_t ldo, int col_off,
+                          int32_t* comp_out, void* stream);
+int dpc_encode_onehot(const int32_t* codes, int64_t N, int dim, double* out64, float* out32,
+                      int64_t ldo, int col_off, void* stream);
+
+/* ---- generator / discriminator glue (dp_cgan.py:31-100) ------------------------------------- */
+/* Column reductions, two steps so that a data-parallel run can all-reduce `part` in between.
+ * mode 0: sum x, sum x^2 (BatchNorm1d batch statistics, :76); 1: sum w[r]*x (bias gradients);
+ * 2: sum dyh, sum dyh*xhat (BatchNorm backward).  part: R*nout*F fp64, R returned in *R_out (host). */
+int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int64_t rows, int F, const float* w,
+                          const float* y, int64_t ldy, const float* z, int64_t ldz, const float* mean,
+                          const float* invstd, double* part, int max_R, int* R_out, void* stream);
+/* kind 0: mean, invstd = f(part, count, eps) and the running-statistics update (momentum);
+ * kind 1/2: plain sums to out0 (and out1). */
+int dpc_colreduce_finish(const double* part, int R, int nout, int F, int kind, double count, float eps,
+                         float momentum, float* out0, float* out1, float* run_mean, float* run_var,
+                         int accumulate, void* stream);
+int dpc_bn_relu_fwd(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    void* stream);
+int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z,
+                    int64_t ldz, int64_t B, int F, const float* mean, const float* invstd,
+                    const float* gamma, const float* dbeta, const float* dgamma, double count,
+                    float* dz, int64_t lddz, void* stream);
+/* last Linear(d, 1) of the discriminator (:43) */
+int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,
+                     float* y, void* stream);
+/* delta[r,j] = rowscale[r] * w[j] * slope[r,j]: seed of the backward / input-gradient chain */
+int dpc_disc_seed(const float* rowscale, const float* w, const float* slope, int64_t lds, int64_t rows,
+                  int d, float* delta, int64_t ldd, void* stream);
+/* interpolates of calc_gradient_penalty (:47-51): one alpha per pac group of group_len elements */
+int dpc_interpolate(const float* real, const float* fake, float* out, int64_t n, int64_t group_len,
+                    const float* alpha_inj, const uint64_t* rng, uint32_t site, float* alpha_out,
+                    void* stream);
+/* (:61-62) in place g0 -> coef*(||g0||-1)/||g0|| * g0, pen_rows[r] = (||g0||-1)^2 */
+int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef, double* pen_rows, float* nrm_out,
+                void* stream);
+int dpc_sum_f64(const double* v, int64_t n, double scale, float* out, int accumulate, void* stream);
+int dpc_mean_pair(const float* y, int64_t n, float sa, float sb, float* out, int accumulate,
+                  void* stream);
+
+/* ---- gradient post-processing + optimiser (dp_cgan.py:510-518, 638-661) ---------------------- */
+/* One launch over a flat parameter buffer: g_eff = gscale*g + seg_add[segment] + noise_scale*noise,
+ * coupled-L2 Adam, optional clamp to +-clamp.  t = *t_dev + 1 when t_dev != NULL else t_host.
+ * seg_off int64 [nseg+1] device, seg_add fp32 [nseg] device (the reference's per-tensor scalar
+ * hook noise); noise_inj fp32 [n] or Philox normal idx i. */
+int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                  float eps, float wd, float clamp, float gscale, const int32_t* t_dev, int t_host,
+                  const int64_t* seg_off, const float* seg_add, int nseg, float noise_scale,
+                  const float* noise_inj, const uint64_t* rng, uint32_t site, void* stream);
+/* x = clamp(x + scale * noise): the stand-alone DP noise-add (+ weight clamp) kernel */
+int dpc_noise_add_clamp(float* x, int64_t n, float scale, const float* noise_inj, const uint64_t* rng,
+                        uint32_t site, float clamp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,435 @@
+"""Per-kernel parity: HIP kernels (through the C-ABI) vs the CPU oracle / golden fixtures.
+Tolerance for fp32 results: 1e-5 relative to the tensor's scale (north_star); integer / index
+results are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Trace, load
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=RTOL, what='', scale=None):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    sc = max(np.abs(b).max(), 1e-30) if scale is None else scale
+    err = np.abs(a - b).max() / sc
+    assert err <= rtol, '%s: max err / scale = %.3e' % (what, err)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dp_cgans_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(50, 64, 940), (500, 256, 166), (300, 56, 678), (1, 1, 1), (64, 64, 16),
+                                   (129, 67, 33), (1024, 256, 4888), (3072, 335, 916), (257, 4888, 256)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
+def test_gemm_shapes(ops, M, N, K, ta, tb):
+    if M * N * K > 3e9:
+        pytest.skip('big')
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    C = torch.full((M, N), float('nan'), device=dev())
+    ops.gemm(A.to(dev()), B.to(dev()), C, trans_a=ta, trans_b=tb)
+    close(C, ref, what='gemm %dx%dx%d' % (M, N, K))
+
+
+def test_gemm_strided_views_bias_beta_and_unaligned(ops):
+    g = torch.Generator().manual_seed(5)
+    # operands that are column slices of wider buffers (the concat-free generator layout), odd ld
+    X = torch.randn(130, 333, generator=g).to(dev())
+    W = torch.randn(77, 201, generator=g).to(dev())
+    bias = torch.randn(77, generator=g).to(dev())
+    Cbuf = torch.randn(130, 99, generator=g).to(dev())
+    C0 = Cbuf.clone()
+    xin = X[:, 132:333]           # [130, 201], ld 333, start not 16-byte aligned
+    out = Cbuf[:, 5:82]
+    ops.gemm(xin, W, out, trans_b=True, bias=bias, alpha=0.5, beta=2.0)
+    ref = 0.5 * (xin.double().cpu() @ W.double().cpu().t()) + bias.double().cpu() + 2.0 * C0[:, 5:82].double().cpu()
+    close(out, ref, what='strided gemm')
+    assert torch.equal(Cbuf[:, :5], C0[:, :5]) and torch.equal(Cbuf[:, 82:], C0[:, 82:])
+
+
+@pytest.mark.parametrize('splitk', [1, 4, 0])
+def test_gemm_weight_gradient_shape_splitk(ops, splitk):
+    g = torch.Generator().manual_seed(9)
+    dY = torch.randn(8192, 256, generator=g).to(dev())
+    X = torch.randn(8192, 404, generator=g).to(dev())
+    dW = torch.zeros(256, 404, device=dev())
+    ops.gemm(dY, X, dW, trans_a=True, splitk=splitk)
+    close(dW, dY.double().cpu().t() @ X.double().cpu(), what='dW splitk=%d' % splitk)
+    acc = dW.clone()
+    ops.gemm(dY, X, dW, trans_a=True, beta=1.0, splitk=splitk)
+    close(dW, 2 * acc.double().cpu(), what='dW accumulate')
+
+
+def test_gemm_epilogues(ops):
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(96, 300, generator=g)
+    W = torch.randn(70, 300, generator=g)
+    b = torch.randn(70, generator=g)
+    keep = (torch.rand(96, 70, generator=g) > 0.5).to(torch.uint8)
+    pre = X.double() @ W.double().t() + b.double()
+    slope = torch.where(pre > 0, 1.0, 0.2) * keep.double() * 2
+    H = torch.empty(96, 70, device=dev())
+    S = torch.empty(96, 70, device=dev())
+    ops.gemm(X.to(dev()), W.to(dev()), H, trans_b=True, bias=b.to(dev()), epi=ops.EPI_LEAKY_DROPOUT, aux_out=S,
+             keep=keep.to(dev()))
+    close(S, slope, what='slope')
+    close(H, pre * slope, what='leaky dropout')
+    # Philox mask: the epilogue must use exactly the bits dpc_fill(kind=KEEP) exposes
+    rng = ops.new_rng(1234, dev())
+    kb = torch.empty(96, 70, dtype=torch.uint8, device=dev())
+    ops.fill(kb, ops.FILL_KEEP, rng, 17)
+    ops.gemm(X.to(dev()), W.to(dev()), H, trans_b=True, bias=b.to(dev()), epi=ops.EPI_LEAKY_DROPOUT, aux_out=S,
+             rng=rng, site=17)
+    slope2 = torch.where(pre > 0, 1.0, 0.2) * kb.cpu().double() * 2
+    close(S, slope2, what='slope philox')
+    assert 0.4 < kb.float().mean().item() < 0.6
+    # multiply epilogue
+    Mul = torch.randn(96, 70, generator=g)
+    ops.gemm(X.to(dev()), W.to(dev()), H, trans_b=True, epi=ops.EPI_MUL, aux_in=Mul.to(dev()))
+    close(H, (X.double() @ W.double().t()) * Mul.double(), what='mul epilogue')
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    A = torch.zeros(4, 4, device=dev())
+    with pytest.raises(ValueError):
+        ops.gemm(A, torch.zeros(5, 4, device=dev()), A)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, A, A, epi=ops.EPI_MUL)       # aux_in missing
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG, noise add, Adam
+# ------------------------------------------------------------------------------------------------
+def test_philox_fills_and_noise_add(ops):
+    rng = ops.new_rng(42, dev())
+    n = 1 << 20
+    z = torch.empty(n, device=dev())
+    ops.fill(z, ops.FILL_NORMAL, rng, 3)
+    z2 = torch.empty(n, device=dev())
+    ops.fill(z2, ops.FILL_NORMAL, rng, 3)
+    assert torch.equal(z, z2)                       # same (seed, step, site) -> same stream
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    ops.fill(z2, ops.FILL_NORMAL, rng, 4)
+    assert not torch.equal(z, z2)                   # other site
+    ops.state_advance(rng)
+    ops.fill(z2, ops.FILL_NORMAL, rng, 3)
+    assert not torch.equal(z, z2)                   # other step
+    assert rng.cpu().tolist() == [42, 1]
+    e = torch.empty(n, device=dev())
+    ops.fill(e, ops.FILL_EXP, rng, 5)
+    assert abs(e.mean().item() - 1) < 5e-3 and e.min().item() > 0
+    u = torch.empty(n, dtype=torch.float64, device=dev())
+    ops.fill(u, ops.FILL_UNIFORM64, rng, 6)
+    assert 0 <= u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 2e-3
+
+    # noise_add_clamp with Philox == with the injected tensor of the same draws; and vs numpy
+    x0 = torch.randn(n + 3, device=dev()) * 0.01
+    zz = torch.empty(n + 3, device=dev())
+    ops.fill(zz, ops.FILL_NORMAL, rng, 7)
+    xa = ops.noise_add_clamp(x0.clone(), 0.002, rng=rng, site=7, clamp=0.01)
+    xb = ops.noise_add_clamp(x0.clone(), 0.002, noise_inj=zz, clamp=0.01)
+    assert torch.equal(xa, xb)
+    ref = np.clip(x0.cpu().numpy() + np.float32(0.002) * zz.cpu().numpy(), -0.01, 0.01)
+    close(xa, ref, what='noise_add_clamp')
+
+
+@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz'])
+def test_adam_matches_reference_trace(ops, name):
+    """Replay the discriminator's optimiser steps of the reference trace on the flat-buffer kernel."""
+    tr = Trace(name)
+    steps = [s for s, k in enumerate(tr.kinds) if k == 'D']
+    p0 = tr.params(steps[0], 'p_before')
+    sizes = [p0[k].size for k in tr.dkeys]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    flat = lambda d: torch.from_numpy(np.concatenate([d[k].reshape(-1) for k in tr.dkeys])).to(dev())
+    p = flat(p0)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    t_dev = torch.zeros(1, dtype=torch.int32, device=dev())
+    for s in steps:
+        g = flat(tr.params(s, 'g'))
+        ops.adam_step(p, g, m, v, 2e-4, 1e-6, t_dev=t_dev)
+        ops.state_advance(t_a=t_dev)
+        ref = flat(tr.params(s, 'p_after'))
+        close(p, ref, what='adam step %d' % s)
+        if tr.private:
+            p.clamp_(-0.01, 0.01)
+    fin = torch.from_numpy(np.concatenate([tr.z['disc_final/' + k].reshape(-1) for k in tr.dkeys]))
+    close(p, fin, what='final D params')
+    # fused form: hook-noise segments + clamp inside the kernel == separate ops
+    if tr.private:
+        s = steps[0]
+        p1 = flat(p0); m1 = torch.zeros_like(p1); v1 = torch.zeros_like(p1)
+        seg_add = torch.randn(len(sizes), device=dev()) * 0.01
+        seg_off = torch.from_numpy(off.astype(np.int64)).to(dev())
+        g = flat(tr.params(s, 'g'))
+        ops.adam_step(p1, g, m1, v1, 2e-4, 1e-6, t_host=1, seg_off=seg_off, seg_add=seg_add, clamp=0.01)
+        g2 = g + torch.repeat_interleave(seg_add, torch.tensor(sizes, device=dev()))
+        p2 = flat(p0); m2 = torch.zeros_like(p2); v2 = torch.zeros_like(p2)
+        ops.adam_step(p2, g2, m2, v2, 2e-4, 1e-6, t_host=1)
+        close(p1, p2.clamp(-0.01, 0.01), what='fused segment noise + clamp')
+
+
+# ------------------------------------------------------------------------------------------------
+# activation + cond loss
+# ------------------------------------------------------------------------------------------------
+def span_table(span_info):
+    rows, st = [], 0
+    for dim, sm, _ in span_info.tolist():
+        rows.append((st, dim, sm))
+        st += dim
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def col_maps(span_info):
+    from oracle.nets import discrete_columns
+    Dd = int(span_info[:, 0].sum())
+    col2d = -np.ones(Dd, dtype=np.int32)
+    col2c = np.zeros(Dd, dtype=np.int32)
+    for d, (ds, cs, k) in enumerate(discrete_columns(span_info)):
+        col2d[ds:ds + k] = d
+        col2c[ds:ds + k] = np.arange(cs, cs + k)
+    return torch.from_numpy(col2d), torch.from_numpy(col2c)
+
+
+def test_apply_activate_matches_reference_trace(ops):
+    from oracle import nets as onets
+    tr = Trace('trace_np.npz')
+    spans = span_table(tr.span_info).to(dev())
+    for s in range(tr.n_steps):
+        fake = torch.from_numpy(tr.get(s, 'fake'))
+        expn = torch.from_numpy(tr.exp_full(s))
+        y = torch.full((tr.B, fake.shape[1] + 7), float('nan'), device=dev())    # wider destination (ld > Dd)
+        ops.apply_activate_fwd(fake.to(dev()), y[:, :fake.shape[1]], spans, exp_noise=expn.to(dev()))
+        close(y[:, :fake.shape[1]], tr.get(s, 'fakeact'), what='fakeact step %d' % s)
+        assert torch.isnan(y[:, fake.shape[1]:]).all()
+    # backward vs autograd of the oracle
+    fake = torch.from_numpy(tr.get(0, 'fake')).requires_grad_(True)
+    expn = torch.from_numpy(tr.exp_full(0))
+    yo = onets.apply_activate(fake, tr.span_info, expn)
+    dy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))
+    (gref,) = torch.autograd.grad(yo, fake, dy)
+    dx = torch.ones_like(dy).to(dev())
+    ops.apply_activate_bwd(yo.detach().to(dev()), dy.to(dev()), dx, spans, accumulate=False)
+    close(dx, gref, what='activate bwd')
+    ops.apply_activate_bwd(yo.detach().to(dev()), dy.to(dev()), dx, spans, accumulate=True)
+    close(dx, 2 * gref, what='activate bwd accumulate')
+    # Philox path == injected path fed with the exposed draws
+    rng = ops.new_rng(7, dev())
+    B, Dd = fake.shape
+    e = torch.empty(B, Dd, device=dev())
+    ops.fill(e, ops.FILL_EXP, rng, ops.SITE_GUMBEL)
+    ya = torch.empty(B, Dd, device=dev())
+    yb = torch.empty(B, Dd, device=dev())
+    ops.apply_activate_fwd(fake.detach().to(dev()), ya, spans, rng=rng)
+    ops.apply_activate_fwd(fake.detach().to(dev()), yb, spans, exp_noise=e)
+    assert torch.equal(ya, yb)
+    close(ya, onets.apply_activate(fake.detach(), tr.span_info, e.cpu()), what='philox gumbel vs oracle')
+
+
+def test_cond_loss_matches_reference_and_oracle(ops):
+    from oracle import nets as onets
+    tr = Trace('trace_np.npz')
+    col2d, col2c = col_maps(tr.span_info)
+    nd = len(onets.discrete_columns(tr.span_info))
+    part = torch.empty(2048, dtype=torch.float64, device=dev())
+    for s, kind in enumerate(tr.kinds):
+        if kind != 'G':
+            continue
+        fake = torch.from_numpy(tr.get(s, 'fake')).requires_grad_(True)
+        cond, mask = torch.from_numpy(tr.get(s, 'cond')), torch.from_numpy(tr.get(s, 'mask'))
+        ref = onets.cond_loss_pair_loop(fake, cond, mask, tr.span_info)
+        (gref,) = torch.autograd.grad(ref, fake)
+        loss = torch.zeros(1, device=dev())
+        dfake = torch.full(fake.shape, float('nan'), device=dev())
+        ops.cond_loss(fake.detach().to(dev()), cond.to(dev()), mask.to(dev()), col2d.to(dev()), col2c.to(dev()), nd,
+                      loss, dfake, part)
+        close(loss, [float(tr.get(s, 'ce'))], what='ce vs reference')
+        close(loss, [float(ref)], what='ce vs oracle loop')
+        close(dfake, gref, what='d ce / d fake')
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler
+# ------------------------------------------------------------------------------------------------
+def sampler_device_tables(ops, enc, span_info):
+    from oracle.nets import discrete_columns
+    cols = discrete_columns(span_info)
+    cat_col = np.concatenate([np.arange(ds, ds + k) for ds, _, k in cols]).astype(np.int32)
+    cond_st = np.array([c[1] for c in cols], dtype=np.int32)
+    dims = np.array([c[2] for c in cols], dtype=np.int32)
+    N, C = enc.shape[0], len(cat_col)
+    W = (N + 63) // 64
+    table = torch.from_numpy(enc.astype(np.float32)).to(dev())
+    bitmaps = torch.zeros(C, W, dtype=torch.int64, device=dev())
+    cnt = torch.zeros(C, C, dtype=torch.int32, device=dev())
+    ops.build_bitmaps(table, torch.from_numpy(cat_col).to(dev()), bitmaps)
+    ops.cooccurrence(bitmaps, cnt)
+    return table, bitmaps, cnt, torch.from_numpy(cond_st).to(dev()), torch.from_numpy(dims).to(dev()), cat_col
+
+
+def test_sampler_bit_exact_against_reference(ops):
+    from oracle import sampler as osamp
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    table, bitmaps, cnt, cond_st, dims, cat_col = sampler_device_tables(ops, enc, span)
+    onehot = enc[:, cat_col]
+    assert np.array_equal(cnt.cpu().numpy(), (onehot.T @ onehot).astype(np.int32))
+    B = int(z['call/B'])
+    C, nd = cnt.shape[0], dims.shape[0]
+    cond = torch.full((B, C), -1.0, device=dev())
+    cond2 = torch.full((B, C + 3), -1.0, device=dev())
+    mask = torch.full((B, nd), -1, dtype=torch.int32, device=dev())
+    pid = torch.empty(B, dtype=torch.int64, device=dev())
+    vid = torch.empty(B, dtype=torch.int64, device=dev())
+    sel = torch.empty(B, 2, dtype=torch.int32, device=dev())
+    gcount = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.condvec_pair_sample(cnt, cond_st, dims, enc.shape[0], B, [cond, cond2[:, 3:]], mask, pid, vid, sel, gcount,
+                            pairs_inj=torch.from_numpy(z['call/pairs'].astype(np.int32)).to(dev()),
+                            r_inj=torch.from_numpy(z['call/r']).to(dev()))
+    assert np.array_equal(cond.cpu().numpy(), z['call/cond'])
+    assert np.array_equal(cond2[:, 3:].cpu().numpy(), z['call/cond'])
+    assert np.array_equal(mask.cpu().numpy(), z['call/mask'])
+    assert np.array_equal(pid.cpu().numpy(), z['call/pair_id'])
+    assert np.array_equal(vid.cpu().numpy(), z['call/val_idx'])
+    # row pick: rank k of the reference's pick inside its ascending list -> same row id
+    tb = osamp.Tables(enc, span)
+    perm = z['call/perm']
+    k = osamp.rank_of_row(tb, z['call/pair_id'][perm], z['call/val_idx'][perm], z['call/row_ids'])
+    assert np.array_equal(gcount.cpu().numpy()[perm], osamp.group_sizes(tb, z['call/pair_id'][perm], z['call/val_idx'][perm]))
+    row_id = torch.empty(B, dtype=torch.int64, device=dev())
+    permd = torch.from_numpy(perm.astype(np.int64)).to(dev())
+    ops.row_select(bitmaps, sel, gcount, row_id, perm=permd, k_inj=torch.from_numpy(k).to(dev()))
+    assert np.array_equal(row_id.cpu().numpy(), z['call/row_ids'])
+    Dd = enc.shape[1]
+    out = torch.full((B, Dd + C), -1.0, device=dev())
+    ops.row_gather(table, row_id, out, Dd, sel=sel, perm=permd, C=C)
+    assert np.array_equal(out[:, :Dd].cpu().numpy(), z['call/real'].astype(np.float32))
+    assert np.array_equal(out[:, Dd:].cpu().numpy(), z['call/cond'][perm])
+    # every rank of one group returns the group's rows in ascending order
+    p0, v0 = int(z['call/pair_id'][0]), int(z['call/val_idx'][0])
+    rows = tb.pair_rows[p0][v0]
+    sel1 = sel[0:1].repeat(len(rows), 1).contiguous()
+    gc1 = gcount[0:1].repeat(len(rows)).contiguous()
+    rid = torch.empty(len(rows), dtype=torch.int64, device=dev())
+    ops.row_select(bitmaps, sel1, gc1, rid, k_inj=torch.arange(len(rows), device=dev()))
+    assert np.array_equal(rid.cpu().numpy(), rows)
+
+
+def test_sampler_philox_draws_are_valid_and_distributed(ops):
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    table, bitmaps, cnt, cond_st, dims, cat_col = sampler_device_tables(ops, enc, span)
+    B = 8192
+    C, nd = cnt.shape[0], dims.shape[0]
+    rng = ops.new_rng(99, dev())
+    cond = torch.empty(B, C, device=dev())
+    mask = torch.empty(B, nd, dtype=torch.int32, device=dev())
+    pid = torch.empty(B, dtype=torch.int64, device=dev())
+    vid = torch.empty(B, dtype=torch.int64, device=dev())
+    sel = torch.empty(B, 2, dtype=torch.int32, device=dev())
+    gcount = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.condvec_pair_sample(cnt, cond_st, dims, enc.shape[0], B, [cond], mask, pid, vid, sel, gcount, rng=rng)
+    assert (cond.sum(1) == 2).all() and (mask.sum(1) == 2).all()
+    assert 0 <= pid.min().item() and pid.max().item() < nd * (nd - 1) // 2
+    assert len(torch.unique(pid)) == nd * (nd - 1) // 2          # every pair shows up at B = 8192
+    perm = torch.empty(B, dtype=torch.int64, device=dev())
+    keys = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.random_perm(rng, perm, keys)
+    assert torch.equal(torch.sort(perm).values, torch.arange(B, device=dev()))
+    row_id = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.row_select(bitmaps, sel, gcount, row_id, perm=perm, rng=rng)
+    assert row_id.min().item() >= 0 and row_id.max().item() < enc.shape[0]
+    # the picked row really has both categories of the (permuted) request
+    onehot = torch.from_numpy(enc[:, cat_col].astype(np.float32)).to(dev())
+    s = sel[perm].long()
+    assert (onehot[row_id, s[:, 0]] == 1).all() and (onehot[row_id, s[:, 1]] == 1).all()
+
+
+def test_encode_bit_exact_against_reference(ops):
+    from oracle import encode as oenc
+    z = load('adult_encode.npz')
+    table, enc, span = z['table'], z['encoded'], z['span_info'].tolist()
+    N = table.shape[0]
+    Dd = enc.shape[1]
+    out64 = torch.full((N, Dd), -7.0, dtype=torch.float64, device=dev())
+    out32 = torch.full((N, Dd), -7.0, device=dev())
+    us = z['choice_u'].reshape(len(z['continuous_columns']), -1)
+    cont = z['continuous_columns'].tolist()
+    st, ci, si, j = 0, 0, 0, 0
+    while si < len(span):
+        ncol = span[si][2]
+        width = sum(span[si + t][0] for t in range(ncol))
+        if ci in cont:
+            g = lambda k: z['gm%d/%s' % (ci, k)]
+            A = oenc.gm_constants(g('weight_concentration_a'), g('weight_concentration_b'), g('mean_precision'),
+                                  g('degrees_of_freedom'), g('precisions_cholesky'))
+            tab = np.stack([g('means'), np.sqrt(g('covariances')), g('precisions_cholesky'), A])
+            valid = np.nonzero(g('valid'))[0].astype(np.int32)
+            x = torch.from_numpy(np.ascontiguousarray(table[:, ci])).to(dev())
+            ops.encode_continuous(x, torch.from_numpy(tab).to(dev()), torch.from_numpy(valid).to(dev()), out64=out64,
+                                  out32=out32, col_off=st, u_inj=torch.from_numpy(us[j]).to(dev()))
+            j += 1
+        else:
+            dummies = z['ohe%d/dummies' % ci]
+            codes = np.array([int(np.where(dummies == v)[0][0]) for v in table[:, ci]], dtype=np.int32)
+            ops.encode_onehot(torch.from_numpy(codes).to(dev()), width, out64=out64, out32=out32, col_off=st)
+        st += width
+        si += ncol
+        ci += 1
+    assert np.array_equal(out64.cpu().numpy(), enc)
+    assert np.array_equal(out32.cpu().numpy(), enc.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm pieces
+# ------------------------------------------------------------------------------------------------
+def test_batchnorm_relu_forward_backward(ops):
+    torch.manual_seed(0)
+    B, F = 1000, 130
+    z = (torch.randn(B, F) * 3 + 1.5)
+    gamma, beta = torch.rand(F) + 0.5, torch.randn(F) * 0.1
+    zz = z.clone().requires_grad_(True)
+    gg, bb = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(F), torch.ones(F)
+    y_ref = torch.relu(torch.nn.functional.batch_norm(zz, rm, rv, gg, bb, True, 0.1, 1e-5))
+    dy = torch.randn(B, F)
+    gz, ggam, gbet = torch.autograd.grad(y_ref, [zz, gg, bb], dy)
+    d = dev()
+    part = torch.empty(64 * 2 * F, dtype=torch.float64, device=d)
+    mean, invstd = torch.empty(F, device=d), torch.empty(F, device=d)
+    run_m, run_v = torch.zeros(F, device=d), torch.ones(F, device=d)
+    zd = z.to(d)
+    R = ops.colreduce_partial(0, zd, part)
+    ops.colreduce_finish(part, R, 2, F, 0, mean, invstd, count=B, run_mean=run_m, run_var=run_v)
+    y = torch.empty(B, F, device=d)
+    ops.bn_relu_fwd(zd, y, mean, invstd, gamma.to(d), beta.to(d))
+    close(y, y_ref.detach(), what='bn relu fwd')
+    close(run_m, rm, what='running mean')
+    close(run_v, rv, what='running var')
+    dbeta, dgamma = torch.empty(F, device=d), torch.empty(F, device=d)
+    R = ops.colreduce_partial(2, dy.to(d), part, y=y, z=zd, mean=mean, invstd=invstd)
+    ops.colreduce_finish(part, R, 2, F, 2, dbeta, dgamma)
+    close(dbeta, gbet, what='dbeta')
+    close(dgamma, ggam, what='dgamma')
+    dz = torch.empty(B, F, device=d)
+    ops.bn_relu_bwd(dy.to(d), y, zd, mean, invstd, gamma.to(d), dbeta, dgamma, B, dz)
+    close(dz, gz, what='dz')
