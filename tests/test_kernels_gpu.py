@@ -263,7 +263,7 @@ def test_cond_loss_matches_reference_and_oracle(ops):
         ops.cond_loss(fake.detach().to(dev()), cond.to(dev()), mask.to(dev()), col2d.to(dev()), col2c.to(dev()), nd,
                       loss, dfake, part)
         close(loss, [float(tr.get(s, 'ce'))], what='ce vs reference')
-        close(loss, [float(ref)], what='ce vs oracle loop')
+        close(loss, [float(ref.detach())], what='ce vs oracle loop')
         close(dfake, gref, what='d ce / d fake')
 
 
@@ -278,7 +278,7 @@ def sampler_device_tables(ops, enc, span_info):
     dims = np.array([c[2] for c in cols], dtype=np.int32)
     N, C = enc.shape[0], len(cat_col)
     W = (N + 63) // 64
-    table = torch.from_numpy(enc.astype(np.float32)).to(dev())
+    table = torch.from_numpy(np.ascontiguousarray(enc, dtype=np.float32)).to(dev())
     bitmaps = torch.zeros(C, W, dtype=torch.int64, device=dev())
     cnt = torch.zeros(C, C, dtype=torch.int32, device=dev())
     ops.build_bitmaps(table, torch.from_numpy(cat_col).to(dev()), bitmaps)
