@@ -1,0 +1,448 @@
+"""Host-side executor of one DP-CGAN training step on the HIP kernels.
+
+Mirrors what DPCGANSynthesizer.fit does per step (reference dp_cgan.py:577-661 discriminator
+update, :673-722 generator update) but issues hand-written gfx950 kernels through the C-ABI
+instead of ATen ops + autograd.  torch is used for device memory and streams only.
+
+Memory layout (all fp32, row-major, resident in HBM for the whole fit):
+  gen params / grads / Adam m,v   one flat buffer each; state_dict tensors are views into it
+  disc params / grads / Adam m,v  one flat buffer each
+  Hg  [B, sum(g)+E+C]             generator activations, concat-free: [h_{L-1} | .. | h_0 | z | c];
+                                  layer l reads the suffix that starts after its own output block,
+                                  which is exactly torch.cat([out, input]) of Residual (dp_cgan.py:83)
+  Xd  [3B, Dd+C] = [3n, K0]       stacked discriminator input: rows 0..n-1 fake groups, n..2n-1 real
+                                  groups, 2n..3n-1 interpolates (later overwritten by the penalty's
+                                  v-chain so that one GEMM per layer yields loss + penalty weight grads)
+  H_i, S_i, D_i [3n, d_i]         activations, slopes (mask*2*{1,.2}), backward deltas per hidden layer
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+GP_LAMBDA = 10.0
+LEAK = 0.2
+TAU = 0.2
+
+
+def span_tables(span_info):
+    """span_info int [n,3] (dim, is_softmax, spans_in_column) -> spans int32 [n,3] (offset, dim, kind),
+    discrete columns [(data_off, cond_off, dim)], col2d / col2c int32 [Dd]."""
+    spans, cols, st, cst = [], [], 0, 0
+    for dim, sm, ncol in np.asarray(span_info).tolist():
+        spans.append((st, dim, 1 if sm else 0))
+        if sm and ncol == 1:
+            cols.append((st, cst, dim))
+            cst += dim
+        st += dim
+    Dd = st
+    col2d = -np.ones(Dd, dtype=np.int32)
+    col2c = np.zeros(Dd, dtype=np.int32)
+    for d, (ds, cs, k) in enumerate(cols):
+        col2d[ds:ds + k] = d
+        col2c[ds:ds + k] = np.arange(cs, cs + k)
+    return np.array(spans, dtype=np.int32).reshape(-1, 3), cols, col2d, col2c
+
+
+class FlatParams(object):
+    """Named views into one flat fp32 buffer (+ grads and Adam moments of the same layout)."""
+
+    def __init__(self, shapes, device):
+        self.keys = [k for k, _ in shapes]
+        self.shapes = dict(shapes)
+        sizes = [int(np.prod(s)) for _, s in shapes]
+        # keep every tensor 16-byte aligned inside the flat buffer (float4 loads in the GEMM)
+        self.offsets, off = {}, 0
+        for k, n in zip(self.keys, sizes):
+            self.offsets[k] = off
+            off += (n + 3) // 4 * 4
+        self.n = off
+        self.p = torch.zeros(off, device=device)
+        self.g = torch.zeros(off, device=device)
+        self.m = torch.zeros(off, device=device)
+        self.v = torch.zeros(off, device=device)
+        self.t = torch.zeros(1, dtype=torch.int32, device=device)
+        seg = [self.offsets[k] for k in self.keys] + [off]
+        self.seg_off = torch.tensor(seg, dtype=torch.int64, device=device)
+
+    def view(self, buf, k):
+        o = self.offsets[k]
+        return buf[o:o + int(np.prod(self.shapes[k]))].view(self.shapes[k])
+
+    def P(self, k):
+        return self.view(self.p, k)
+
+    def G(self, k):
+        return self.view(self.g, k)
+
+    def load(self, sd):
+        for k in self.keys:
+            self.P(k).copy_(torch.as_tensor(sd[k]).to(self.p.device, torch.float32))
+
+    def state_dict(self):
+        return {k: self.P(k).detach().clone() for k in self.keys}
+
+
+def _linear_init(w, b, gen):
+    """torch.nn.Linear default init (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)) for both)."""
+    bound = 1.0 / math.sqrt(w.shape[1])
+    w.copy_((torch.rand(w.shape, generator=gen) * 2 - 1) * bound)
+    b.copy_((torch.rand(b.shape, generator=gen) * 2 - 1) * bound)
+
+
+class NoDist(object):
+    world = 1
+    rank = 0
+
+    def allreduce(self, t):
+        return t
+
+
+class StepEngine(object):
+    def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
+                 generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
+                 private=False, seed=0, dist=None, global_batch=None):
+        self.dev = torch.device(device)
+        self.dist = dist or NoDist()
+        spans, cols, col2d, col2c = span_tables(span_info)
+        self.Dd = int(spans[:, 1].sum())
+        self.nd = len(cols)
+        self.C = int(sum(c[2] for c in cols))
+        self.E, self.B, self.pac = embedding_dim, batch_size, pac
+        if batch_size % pac != 0:
+            raise AssertionError('batch_size %% pac != 0')      # dp_cgan.py:67
+        self.gB = global_batch or batch_size * self.dist.world
+        self.n = batch_size // pac
+        self.gn = self.gB // pac
+        self.gdim, self.ddim = list(generator_dim), list(discriminator_dim)
+        self.private = private
+        self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
+        d = self.dev
+        self.spans = torch.from_numpy(spans).to(d)
+        self.col2d = torch.from_numpy(col2d).to(d)
+        self.col2c = torch.from_numpy(col2c).to(d)
+        self.has_cond = self.nd > 0
+        L, M = len(self.gdim), len(self.ddim)
+        self.L, self.M = L, M
+        self.Wtot = sum(self.gdim) + self.E + self.C
+        self.start = [sum(self.gdim[l:]) for l in range(L)] + [0]      # start[l] = first input column of layer l
+        self.row = self.Dd + self.C
+        self.K0 = pac * self.row
+        # ---- parameters ------------------------------------------------------------------------
+        gs = []
+        for l in range(L):
+            fan_in = self.Wtot - self.start[l]
+            gs += [('seq.%d.fc.weight' % l, (self.gdim[l], fan_in)), ('seq.%d.fc.bias' % l, (self.gdim[l],)),
+                   ('seq.%d.bn.weight' % l, (self.gdim[l],)), ('seq.%d.bn.bias' % l, (self.gdim[l],))]
+        gs += [('seq.%d.weight' % L, (self.Dd, self.Wtot)), ('seq.%d.bias' % L, (self.Dd,))]
+        self.gen = FlatParams(gs, d)
+        ds, k = [], self.K0
+        for i, w in enumerate(self.ddim):
+            ds += [('seq.%d.weight' % (3 * i), (w, k)), ('seq.%d.bias' % (3 * i), (w,))]
+            k = w
+        ds += [('seq.%d.weight' % (3 * M), (1, k)), ('seq.%d.bias' % (3 * M), (1,))]
+        self.disc = FlatParams(ds, d)
+        self.bn_run = {}
+        for l in range(L):
+            self.bn_run['seq.%d.bn.running_mean' % l] = torch.zeros(self.gdim[l], device=d)
+            self.bn_run['seq.%d.bn.running_var' % l] = torch.ones(self.gdim[l], device=d)
+        self.bn_batches = 0
+        self._init_params(seed)
+        # ---- activations / workspaces ----------------------------------------------------------
+        B, n = self.B, self.n
+        f32 = dict(device=d, dtype=torch.float32)
+        self.Hg = torch.zeros(B, self.Wtot, **f32)
+        self.dHg = torch.zeros(B, self.Wtot, **f32)
+        self.Z = [torch.zeros(B, w, **f32) for w in self.gdim]
+        self.dZ = [torch.zeros(B, w, **f32) for w in self.gdim]
+        self.bn_mean = [torch.zeros(w, **f32) for w in self.gdim]
+        self.bn_invstd = [torch.zeros(w, **f32) for w in self.gdim]
+        self.fake = torch.zeros(B, self.Dd, **f32)
+        self.dfake = torch.zeros(B, self.Dd, **f32)
+        self.Xd = torch.zeros(3 * B, self.row, **f32)
+        self.Xd3 = self.Xd.view(3 * n, self.K0)
+        self.dX = torch.zeros(B, self.row, **f32)
+        self.H = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
+        self.S = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
+        self.Dl = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
+        self.y = torch.zeros(3 * n, **f32)
+        rs = torch.empty(3 * n, **f32)
+        rs[:n] = 1.0 / self.gn
+        rs[n:2 * n] = -1.0 / self.gn
+        rs[2 * n:] = 1.0
+        self.rowscale_d = rs
+        self.rowscale_g = torch.full((n,), -1.0 / self.gn, **f32)
+        self.ones_col = torch.ones(2 * n, 1, **f32)
+        self.pen_rows = torch.zeros(n, device=d, dtype=torch.float64)
+        self.losses = torch.zeros(4, **f32)          # loss_d, pen, -mean(y_fake), cond loss
+        maxF = max(self.gdim + self.ddim + [self.Dd, 1])
+        self.part = torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64)
+        self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
+        self.cond = torch.zeros(B, max(self.C, 1), **f32)
+        self.mask = torch.zeros(B, max(self.nd, 1), device=d, dtype=torch.int32)
+        self.pair_id = torch.zeros(B, device=d, dtype=torch.int64)
+        self.val_idx = torch.zeros(B, device=d, dtype=torch.int64)
+        self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
+        self.gcount = torch.zeros(B, device=d, dtype=torch.int64)
+        self.perm = torch.zeros(B, device=d, dtype=torch.int64)
+        self.keys_ws = torch.zeros(B, device=d, dtype=torch.int64)
+        self.row_id = torch.zeros(B, device=d, dtype=torch.int64)
+        self.hook_add = torch.zeros(len(self.disc.keys), **f32)
+        self.rng = ops.new_rng(seed, d)
+        self.d_steps_done = 0
+        self.sampler = None      # DeviceSampler, attached by the caller
+
+    # ------------------------------------------------------------------------------------------
+    def _init_params(self, seed):
+        gen = torch.Generator().manual_seed(seed)
+        for l in range(self.L):
+            w = torch.empty(self.gen.shapes['seq.%d.fc.weight' % l])
+            b = torch.empty(self.gen.shapes['seq.%d.fc.bias' % l])
+            _linear_init(w, b, gen)
+            self.gen.P('seq.%d.fc.weight' % l).copy_(w)
+            self.gen.P('seq.%d.fc.bias' % l).copy_(b)
+            self.gen.P('seq.%d.bn.weight' % l).fill_(1.0)
+            self.gen.P('seq.%d.bn.bias' % l).zero_()
+        w = torch.empty(self.gen.shapes['seq.%d.weight' % self.L])
+        b = torch.empty(self.gen.shapes['seq.%d.bias' % self.L])
+        _linear_init(w, b, gen)
+        self.gen.P('seq.%d.weight' % self.L).copy_(w)
+        self.gen.P('seq.%d.bias' % self.L).copy_(b)
+        for i in range(self.M + 1):
+            w = torch.empty(self.disc.shapes['seq.%d.weight' % (3 * i)])
+            b = torch.empty(self.disc.shapes['seq.%d.bias' % (3 * i)])
+            _linear_init(w, b, gen)
+            self.disc.P('seq.%d.weight' % (3 * i)).copy_(w)
+            self.disc.P('seq.%d.bias' % (3 * i)).copy_(b)
+
+    def generator_state_dict(self):
+        sd = self.gen.state_dict()
+        for k, v in self.bn_run.items():
+            sd[k] = v.detach().clone()
+        for l in range(self.L):
+            sd['seq.%d.bn.num_batches_tracked' % l] = torch.tensor(self.bn_batches, dtype=torch.int64)
+        return sd
+
+    def discriminator_state_dict(self):
+        return self.disc.state_dict()
+
+    # ------------------------------------------------------------------------------------------
+    # pieces
+    # ------------------------------------------------------------------------------------------
+    def _zc(self):
+        z0 = self.start[0]
+        return self.Hg[:, z0:z0 + self.E], self.Hg[:, z0 + self.E:]
+
+    def _draw_inputs(self, inj, need_real):
+        """z, cond vector (+ mask) and, for the discriminator update, the real rows."""
+        zv, cv = self._zc()
+        B, Dd, C = self.B, self.Dd, self.C
+        if 'z' in inj:
+            zv.copy_(inj['z'])
+        else:
+            ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
+        if not self.has_cond:
+            if need_real:
+                raise NotImplementedError('tables without discrete columns are not supported by the device sampler yet')
+            return
+        fake_c = self.Xd[0:B, Dd:]
+        if 'cond' in inj:
+            self.cond.copy_(inj['cond'])
+            self.mask.copy_(inj['mask'])
+            cv.copy_(self.cond)
+            fake_c.copy_(self.cond)
+        else:
+            s = self.sampler
+            ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [self.cond, cv, fake_c], self.mask, self.pair_id,
+                                    self.val_idx, self.sel, self.gcount, pairs_inj=inj.get('pairs'),
+                                    r_inj=inj.get('r'), rng=self.rng)
+        if not need_real:
+            return
+        real = self.Xd[B:2 * B]
+        if 'real' in inj:
+            real[:, :Dd].copy_(inj['real'])
+            real[:, Dd:].copy_(self.cond[inj['perm']])
+        else:
+            s = self.sampler
+            if 'perm' in inj:
+                self.perm.copy_(inj['perm'])
+            else:
+                ops.random_perm(self.rng, self.perm, self.keys_ws)
+            ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
+                           rng=self.rng)
+            ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
+
+    def _gen_forward(self):
+        g = self.gen
+        count = float(self.gB)
+        for l in range(self.L):
+            x = self.Hg[:, self.start[l]:]
+            ops.gemm(x, g.P('seq.%d.fc.weight' % l), self.Z[l], trans_b=True, bias=g.P('seq.%d.fc.bias' % l))
+            R = ops.colreduce_partial(0, self.Z[l], self.part)
+            nel = R * 2 * self.gdim[l]
+            self.dist.allreduce(self.part[:nel])
+            ops.colreduce_finish(self.part, R, 2, self.gdim[l], 0, self.bn_mean[l], self.bn_invstd[l], count=count,
+                                 run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
+                                 run_var=self.bn_run['seq.%d.bn.running_var' % l])
+            ops.bn_relu_fwd(self.Z[l], self.Hg[:, self.start[l + 1]:self.start[l]], self.bn_mean[l], self.bn_invstd[l],
+                            g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
+        self.bn_batches += 1
+        ops.gemm(self.Hg, g.P('seq.%d.weight' % self.L), self.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
+
+    def _activate(self, inj):
+        dst = self.Xd[0:self.B, :self.Dd] if self.has_cond else self.Xd[0:self.B]
+        if self.has_cond:
+            ops.apply_activate_fwd(self.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng)
+        else:
+            # no discrete columns: both networks see the raw generator output (dp_cgan.py:624-626, Q5)
+            ops.apply_activate_fwd(self.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng)
+            dst.copy_(self.fake)
+
+    def _disc_forward(self, rows, inj):
+        d = self.disc
+        x = self.Xd3[0:rows]
+        keeps = inj.get('keep')
+        for i in range(self.M):
+            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][0:rows], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
+                     epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][0:rows], keep=keeps[i] if keeps else None,
+                     rng=self.rng, site=ops.SITE_DROP0 + i, leak=LEAK)
+            x = self.H[i][0:rows]
+        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * self.M)), d.P('seq.%d.bias' % (3 * self.M)), self.y[0:rows])
+
+    def _disc_chain_down(self, rows, rowscale):
+        """D_M = rowscale * w_last * S_M;  D_{i-1} = (D_i W_i) * S_{i-1}."""
+        d, M = self.disc, self.M
+        ops.disc_seed(rowscale, d.P('seq.%d.weight' % (3 * M)), self.S[M - 1][0:rows], self.Dl[M - 1][0:rows])
+        for i in range(M - 1, 0, -1):
+            ops.gemm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
+                     aux_in=self.S[i - 1][0:rows])
+
+    def _colsum(self, x, out, w=None, accumulate=False):
+        R = ops.colreduce_partial(1, x, self.part, w=w)
+        ops.colreduce_finish(self.part, R, 1, x.shape[1], 1, out, accumulate=accumulate)
+
+    # ------------------------------------------------------------------------------------------
+    # discriminator update
+    # ------------------------------------------------------------------------------------------
+    def d_step(self, inj=None, update=True):
+        inj = inj or {}
+        n, B, M, d = self.n, self.B, self.M, self.disc
+        self._draw_inputs(inj, need_real=True)
+        self._gen_forward()
+        self._activate(inj)
+        ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
+                        rng=self.rng)
+        self._disc_forward(3 * n, inj)
+        ops.mean_pair(self.y, n, 1.0, -1.0, self.losses[0:1])
+        # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
+        self._disc_chain_down(3 * n, self.rowscale_d)
+        W1 = d.P('seq.0.weight')
+        gp_rows = slice(2 * n, 3 * n)
+        ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
+        ops.gp_norm(self.Xd3[gp_rows], 2.0 * GP_LAMBDA / self.gn, self.pen_rows)    # -> v0 in place
+        ops.sum_f64(self.pen_rows, GP_LAMBDA / self.gn, self.losses[1:2])
+        prev = self.Xd3
+        for i in range(M):
+            Wi = d.P('seq.%d.weight' % (3 * i))
+            ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True)      # loss + penalty in one product
+            self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1))
+            # v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
+            ops.gemm(prev[gp_rows], Wi, self.H[i][gp_rows], trans_b=True, epi=ops.EPI_MUL, aux_in=self.S[i][gp_rows])
+            prev = self.H[i]
+        self._colsum(prev, d.G('seq.%d.weight' % (3 * M)), w=self.rowscale_d)
+        self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=self.rowscale_d[0:2 * n])
+        if update:
+            self._disc_update(inj)
+        ops.state_advance(self.rng)
+
+    def _disc_update(self, inj):
+        d = self.disc
+        self.dist.allreduce(d.g)
+        seg_add = None
+        if self.private:
+            # reference behaviour (dp_cgan.py:638-647): one scalar N(0,1)/B per parameter
+            # tensor and hook firing; after t discriminator steps each tensor carries t hooks.
+            if 'hook_noise' in inj:
+                self.hook_add.copy_(inj['hook_noise'])
+            else:
+                # both backward passes (penalty, loss_d) fire every hook except the last bias's, which
+                # only loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
+                fires = np.array([2.0] * (len(d.keys) - 1) + [1.0])
+                std = np.sqrt(fires * (self.d_steps_done + 1)) / self.gB
+                ops.fill(self.hook_add, ops.FILL_NORMAL, self.rng, ops.SITE_HOOK, 0.0, 1.0)
+                self.hook_add.mul_(torch.from_numpy(std.astype(np.float32)).to(self.dev))
+            seg_add = self.hook_add
+        ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=0.01 if self.private else 0.0, t_dev=d.t,
+                      seg_off=d.seg_off if seg_add is not None else None, seg_add=seg_add)
+        ops.state_advance(t_a=d.t)
+        self.d_steps_done += 1
+
+    # ------------------------------------------------------------------------------------------
+    # generator update
+    # ------------------------------------------------------------------------------------------
+    def g_step(self, inj=None, update=True):
+        inj = inj or {}
+        n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
+        self._draw_inputs(inj, need_real=False)
+        self._gen_forward()
+        self._activate(inj)
+        self._disc_forward(n, inj)
+        ops.mean_pair(self.y, n, -1.0, 0.0, self.losses[2:3])
+        self._disc_chain_down(n, self.rowscale_g)
+        ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
+        if self.has_cond:
+            ops.apply_activate_bwd(self.Xd[0:B, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
+            ops.cond_loss(self.fake, self.cond, self.mask, self.col2d, self.col2c, self.nd, self.losses[3:4],
+                          self.dfake, self.part_loss, accumulate=True)
+        else:
+            self.dfake.copy_(self.dX)
+            self.losses[3:4].zero_()
+        # generator backward
+        hid = self.start[0]                                    # columns that hold hidden activations
+        WL = g.P('seq.%d.weight' % L)
+        ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True)
+        self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1))
+        if hid > 0:
+            ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
+        count = float(self.gB)
+        for l in range(L - 1, -1, -1):
+            blk = slice(self.start[l + 1], self.start[l])
+            dy, yv = self.dHg[:, blk], self.Hg[:, blk]
+            R = ops.colreduce_partial(2, dy, self.part, y=yv, z=self.Z[l], mean=self.bn_mean[l], invstd=self.bn_invstd[l])
+            self.dist.allreduce(self.part[:R * 2 * self.gdim[l]])
+            dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
+            ops.colreduce_finish(self.part, R, 2, self.gdim[l], 2, dbeta, dgamma)
+            ops.bn_relu_bwd(dy, yv, self.Z[l], self.bn_mean[l], self.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
+                            dgamma, count, self.dZ[l])
+            Wl = g.P('seq.%d.fc.weight' % l)
+            ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True)
+            self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1))
+            w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
+            if w_hid > 0:
+                ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
+        if update:
+            self._gen_update()
+        ops.state_advance(self.rng)
+
+    def _gen_update(self):
+        g = self.gen
+        # BatchNorm gradients were formed from all-reduced statistics already; the rest is summed here
+        self.dist.allreduce(g.g)
+        ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
+        ops.state_advance(t_a=g.t)
+
+    # ------------------------------------------------------------------------------------------
+    def sample_forward(self, cond=None):
+        """Generator forward + activation for DPCGANSynthesizer.sample (BatchNorm in training mode,
+        as the reference never calls .eval(): dp_cgan.py:881, Q2).  Returns the activated batch."""
+        zv, cv = self._zc()
+        ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
+        if self.has_cond:
+            cv.copy_(cond)
+        self._gen_forward()
+        out = torch.empty(self.B, self.Dd, device=self.dev)
+        ops.apply_activate_fwd(self.fake, out, self.spans, rng=self.rng)
+        ops.state_advance(self.rng)
+        return out

@@ -1,0 +1,197 @@
+"""Whole-step parity: the HIP step engine replays the reference's recorded training steps
+(tests/golden/trace_*.npz: every random draw injected) and must reproduce losses, gradient
+penalty, generator outputs, gradients and updated weights within 1e-5 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Trace
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL, what='', scale=None):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    a, b = a.reshape(-1), b.reshape(-1)
+    assert a.shape == b.shape, '%s: %s vs %s' % (what, a.shape, b.shape)
+    sc = max(np.abs(b).max(), 1e-30) if scale is None else scale
+    err = np.abs(a - b).max() / sc
+    assert err <= rtol, '%s: max err / scale = %.3e' % (what, err)
+
+
+class AdamAwareCompare(object):
+    """Adam's update lr*m/(sqrt(v)+eps) is sign-like: for a gradient entry of rounding-noise size
+    (|g| within ~100 eps of zero, e.g. a unit that dropout silenced in every row) the update is
+    decided by summation order, on the reference's side too.  Entries whose reference gradient is
+    below 1e-5 of the tensor's largest are therefore held to |diff| <= lr per step taken so far,
+    all others to 1e-5 relative."""
+
+    def __init__(self, lr=2e-4):
+        self.loose, self.steps, self.lr = {}, 0, lr
+
+    def check(self, key, mine, ref_p, ref_g, what):
+        tiny = np.abs(ref_g) < 1e-5 * max(np.abs(ref_g).max(), 1e-30)
+        self.loose[key] = tiny | self.loose.get(key, np.zeros_like(tiny))
+        lo = self.loose[key]
+        mine = mine.detach().cpu().numpy()
+        sc = max(np.abs(ref_p).max(), 1e-30)
+        err = np.abs(mine - ref_p)
+        assert (err[~lo] / sc).max(initial=0.0) <= RTOL, '%s: %.3e' % (what, (err[~lo] / sc).max())
+        assert err[lo].max(initial=0.0) <= self.lr * self.steps, '%s (noise-sized grads): %.3e' % (what, err[lo].max())
+        assert lo.size < 64 or lo.mean() < 0.5, '%s: too many entries excused (%.2f)' % (what, lo.mean())
+
+
+def make_engine(tr, device='cuda:0'):
+    from dp_cgans_amd.engine import StepEngine
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, tr.B, tr.pac, device, private=bool(tr.private))
+    first_d, first_g = tr.kinds.index('D'), tr.kinds.index('G')
+    eng.disc.load(tr.params(first_d, 'p_before'))
+    eng.gen.load(tr.params(first_g, 'p_before'))
+    return eng
+
+
+def injected(tr, s, dev):
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    inj = dict(z=t(tr.get(s, 'normal')), cond=t(tr.get(s, 'cond')), mask=t(tr.get(s, 'mask')), exp=t(tr.exp_full(s)))
+    groups = tr.masks(s)
+    nh = len(tr.disc_dim)
+    inj['keep'] = [t(np.concatenate([grp[i] for grp in groups], axis=0)) for i in range(nh)]
+    if tr.kinds[s] == 'D':
+        inj['perm'] = t(tr.get(s, 'shuffle').astype(np.int64))
+        inj['real'] = t(tr.get(s, 'real').astype(np.float32))
+        inj['alpha'] = t(tr.get(s, 'rand').reshape(-1).astype(np.float32))
+        if tr.private:
+            tot = np.zeros(len(tr.dkeys), dtype=np.float64)
+            for per_bwd in tr.hook_noise(s):
+                for pid, v in per_bwd.items():
+                    tot[pid] += v
+            inj['hook_noise'] = t((tot / tr.B).astype(np.float32))
+    return inj
+
+
+@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz'])
+def test_engine_replays_reference_training_steps(name):
+    tr = Trace(name)
+    eng = make_engine(tr)
+    dev = eng.dev
+    B, Dd, n = tr.B, eng.Dd, eng.n
+    cmp_d, cmp_g = AdamAwareCompare(), AdamAwareCompare()
+    for s, kind in enumerate(tr.kinds):
+        inj = injected(tr, s, dev)
+        if kind == 'D':
+            eng.d_step(inj)
+            close(eng.fake, tr.get(s, 'fake'), what='s%d fake' % s)
+            close(eng.Xd[0:B, :Dd], tr.get(s, 'fakeact'), what='s%d fakeact' % s)
+            close(eng.y[0:n], tr.get(s, 'd_out', 0), what='s%d y_fake' % s)
+            close(eng.y[n:2 * n], tr.get(s, 'd_out', 1), what='s%d y_real' % s)
+            close(eng.y[2 * n:], tr.get(s, 'd_out', 2), what='s%d y_interp' % s)
+            losses = eng.losses.cpu().numpy()
+            close(losses[1:2], [float(tr.get(s, 'pen'))], what='s%d pen' % s)
+            # loss_d is a difference of two means: judge it on the scale of those means
+            ysc = max(abs(float(tr.get(s, 'd_out', 0).mean())), abs(float(tr.get(s, 'd_out', 1).mean())))
+            close(losses[0:1], [float(tr.get(s, 'backward_value', 1))], scale=ysc, what='s%d loss_d' % s)
+            ref_g = tr.params(s, 'g')
+            for i, k in enumerate(tr.dkeys):
+                mine = eng.disc.G(k)
+                if tr.private:
+                    mine = mine + inj['hook_noise'][i]
+                close(mine, ref_g[k], rtol=2e-5, what='s%d D grad %s' % (s, k))
+            ref_p = tr.params(s, 'p_after')
+            cmp_d.steps += 1
+            for k in tr.dkeys:
+                ref = np.clip(ref_p[k], -0.01, 0.01) if tr.private else ref_p[k]   # recorded before the clamp
+                cmp_d.check(k, eng.disc.P(k), ref, ref_g[k], 's%d D param %s' % (s, k))
+        else:
+            eng.g_step(inj)
+            close(eng.fake, tr.get(s, 'fake'), what='s%d fake' % s)
+            close(eng.Xd[0:B, :Dd], tr.get(s, 'fakeact'), what='s%d fakeact' % s)
+            close(eng.y[0:n], tr.get(s, 'd_out', 0), what='s%d y_fake' % s)
+            losses = eng.losses.cpu().numpy()
+            close(losses[3:4], [float(tr.get(s, 'ce'))], what='s%d ce' % s)
+            close([losses[2] + losses[3]], [float(tr.get(s, 'backward_value', 0))], what='s%d loss_g' % s)
+            ref_g = tr.params(s, 'g')
+            for k in tr.gkeys:
+                # Linear bias in front of BatchNorm: exactly-zero gradient, rounding noise on both sides
+                sc = np.abs(ref_g[k.replace('fc.bias', 'fc.weight')]).max() if 'fc.bias' in k else None
+                close(eng.gen.G(k), ref_g[k], rtol=2e-5, scale=sc, what='s%d G grad %s' % (s, k))
+            ref_p = tr.params(s, 'p_after')
+            cmp_g.steps += 1
+            for k in tr.gkeys:
+                if 'fc.bias' in k:      # Adam amplifies that noise to up to lr per step (see test_oracle_golden)
+                    assert np.abs(eng.gen.P(k).cpu().numpy() - ref_p[k]).max() < 2e-4 * cmp_g.steps
+                else:
+                    cmp_g.check(k, eng.gen.P(k), ref_p[k], ref_g[k], 's%d G param %s' % (s, k))
+    sd = eng.generator_state_dict()
+    for k in tr.z.files:
+        if k.startswith('gen_final/') and 'running' in k:
+            close(sd[k[len('gen_final/'):]], tr.z[k], what=k)
+    assert int(sd['seq.0.bn.num_batches_tracked']) == int(tr.z['gen_final/seq.0.bn.num_batches_tracked'])
+
+
+def test_engine_sampler_path_matches_oracle_on_same_draws():
+    """Philox-driven step: read back the draws the kernels used (dpc_fill exposes the same map),
+    feed them to the CPU oracle, compare losses / gradients / weights."""
+    from golden_util import load
+    from dp_cgans_amd import ops
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import nets as onets
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+    B, E, pac = 120, 24, 10
+    eng = StepEngine(span, E, (40, 24), (48, 16), B, pac, dev, private=False, seed=5)
+    eng.sampler = DataSampler(enc, span, device=dev)
+    gp = {k: v.cpu() for k, v in eng.gen.state_dict().items()}
+    dp = {k: v.cpu() for k, v in eng.disc.state_dict().items()}
+    n, Dd = eng.n, eng.Dd
+
+    def draws(rows):
+        e = torch.empty(B, Dd, device=dev)
+        ops.fill(e, ops.FILL_EXP, eng.rng, ops.SITE_GUMBEL)
+        zz = torch.empty(B, E, device=dev)
+        ops.fill(zz, ops.FILL_NORMAL, eng.rng, ops.SITE_Z)
+        keeps = []
+        for i, w in enumerate(eng.ddim):
+            kb = torch.empty(rows, w, dtype=torch.uint8, device=dev)
+            ops.fill(kb, ops.FILL_KEEP, eng.rng, ops.SITE_DROP0 + i)
+            keeps.append(kb.cpu())
+        al = torch.empty(n, device=dev)
+        ops.fill(al, ops.FILL_UNIFORM, eng.rng, ops.SITE_ALPHA)
+        return e.cpu(), zz.cpu(), keeps, al.cpu()
+
+    # ---- discriminator update
+    e, zz, keeps, al = draws(3 * n)
+    eng.d_step()
+    cond = eng.cond.cpu()
+    perm = eng.perm.cpu()
+    real = eng.Xd[B:2 * B, :Dd].cpu()
+    rid = eng.row_id.cpu().numpy()
+    assert np.array_equal(real.numpy(), enc[rid].astype(np.float32))
+    sel = eng.sel.cpu().numpy()[perm.numpy()]
+    cat_col = eng.sampler.cat_col.cpu().numpy()
+    assert (enc[rid, cat_col[sel[:, 0]]] == 1).all() and (enc[rid, cat_col[sel[:, 1]]] == 1).all()
+    out = onets.d_step_grads(gp, dp, span, pac, zz, cond, perm, real, e, [k[0:n] for k in keeps],
+                             [k[n:2 * n] for k in keeps], [k[2 * n:] for k in keeps], al)
+    losses = eng.losses.cpu().numpy()
+    close(losses[0:1], [float(out['loss_d'])], scale=float(out['y_fake'].abs().mean()), what='loss_d')
+    close(losses[1:2], [float(out['pen'])], what='pen')
+    for k in eng.disc.keys:
+        close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='D grad ' + k)
+    dp2 = onets.apply_update(dp, out['grads'], {'t': 0, 'm': {}, 'v': {}})
+    cmp_d = AdamAwareCompare()
+    cmp_d.steps = 1
+    for k in eng.disc.keys:
+        cmp_d.check(k, eng.disc.P(k), dp2[k].numpy(), out['grads'][k].numpy(), 'D param ' + k)
+    # ---- generator update
+    e, zz, keeps, al = draws(n)
+    eng.g_step()
+    cond, mask = eng.cond.cpu(), eng.mask.cpu()
+    out = onets.g_step_grads(gp, dp2, span, pac, zz, cond, mask, e, keeps)
+    losses = eng.losses.cpu().numpy()
+    close([losses[2] + losses[3]], [float(out['loss_g'])], what='loss_g')
+    for k in eng.gen.keys:
+        sc = float(out['grads'][k.replace('fc.bias', 'fc.weight')].abs().max()) if 'fc.bias' in k else None
+        close(eng.gen.G(k), out['grads'][k], rtol=2e-5, scale=sc, what='G grad ' + k)
