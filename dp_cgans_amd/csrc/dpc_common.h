@@ -69,8 +69,9 @@ __device__ __forceinline__ uint32_t dpc_draw_u32(const uint64_t* rng, uint32_t s
   return p.v[idx & 3];
 }
 
-// (0,1) open interval, 24 bits.
-__device__ __forceinline__ float dpc_u32_to_unit(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// (0,1) open interval, 23 bits: k + 0.5 for k < 2^23 is exact in fp32, so neither 0 nor 1 can come
+// out (with 24 bits the largest value would round up to 1.0 and -log(-log(u)) would be +inf).
+__device__ __forceinline__ float dpc_u32_to_unit(uint32_t x) { return ((x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // [0,1) with 53 bits from two draws (matches the resolution of numpy's random_sample).
 __device__ __forceinline__ double dpc_u64_to_unit(uint32_t hi, uint32_t lo) {

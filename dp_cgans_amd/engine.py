@@ -190,7 +190,10 @@ class StepEngine(object):
         self.keys_ws = torch.zeros(B, device=d, dtype=torch.int64)
         self.row_id = torch.zeros(B, device=d, dtype=torch.int64)
         self.hook_add = torch.zeros(len(self.disc.keys), **f32)
-        self.rng = ops.new_rng(seed, d)
+        # per-rank streams for the batch shard (z, gumbel, dropout, sampling); one stream shared by all
+        # ranks for the DP noise, so that it is added exactly once and replicas stay bit-identical
+        self.rng = ops.new_rng(seed + 7919 * self.dist.rank, d)
+        self.rng_shared = ops.new_rng(seed ^ 0x3c3c3c3c, d)
         self.d_steps_done = 0
         self.sampler = None      # DeviceSampler, attached by the caller
 
@@ -371,12 +374,12 @@ class StepEngine(object):
                 # only loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
                 fires = np.array([2.0] * (len(d.keys) - 1) + [1.0])
                 std = np.sqrt(fires * (self.d_steps_done + 1)) / self.gB
-                ops.fill(self.hook_add, ops.FILL_NORMAL, self.rng, ops.SITE_HOOK, 0.0, 1.0)
+                ops.fill(self.hook_add, ops.FILL_NORMAL, self.rng_shared, ops.SITE_HOOK, 0.0, 1.0)
                 self.hook_add.mul_(torch.from_numpy(std.astype(np.float32)).to(self.dev))
             seg_add = self.hook_add
         ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=0.01 if self.private else 0.0, t_dev=d.t,
                       seg_off=d.seg_off if seg_add is not None else None, seg_add=seg_add)
-        ops.state_advance(t_a=d.t)
+        ops.state_advance(self.rng_shared, t_a=d.t)
         self.d_steps_done += 1
 
     # ------------------------------------------------------------------------------------------
@@ -428,7 +431,12 @@ class StepEngine(object):
 
     def _gen_update(self):
         g = self.gen
-        # BatchNorm gradients were formed from all-reduced statistics already; the rest is summed here
+        if self.dist.world > 1:
+            # BatchNorm gradients were formed from all-reduced column sums, i.e. are global already:
+            # pre-divide so that the sum over ranks below leaves them unchanged
+            for l in range(self.L):
+                g.G('seq.%d.bn.weight' % l).mul_(1.0 / self.dist.world)
+                g.G('seq.%d.bn.bias' % l).mul_(1.0 / self.dist.world)
         self.dist.allreduce(g.g)
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
         ops.state_advance(t_a=g.t)

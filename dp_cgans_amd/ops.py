@@ -17,6 +17,11 @@ SITE_Z, SITE_GUMBEL, SITE_DROP0, SITE_ALPHA, SITE_CONDVEC, SITE_ROWPICK, SITE_PE
 SITE_NOISE_D, SITE_HOOK, SITE_ENCODE = 7, 8, 9
 
 
+# When set to a list, gemm() brackets every launch with HIP events on the launch stream and appends
+# (start_event, end_event, flops, tag); bench.py uses it for the live roofline measurement.
+GEMM_PROFILE = None
+
+
 def _p(t):
     if t is None:
         return None
@@ -83,10 +88,17 @@ def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, 
     K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
     if K != K2 or C.shape[0] != M or C.shape[1] != N:
         raise ValueError('gemm shape mismatch: op(A) %dx%d, op(B) %dx%d, C %s' % (M, K, K2, N, tuple(C.shape)))
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     lib().call('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
                epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
                _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
                site, leak, splitk, _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b)))
     return C
 
 

@@ -1,0 +1,45 @@
+"""Data parallelism for the training step: one process per GPU, torch.distributed (backend "nccl"
+is RCCL on ROCm) over xGMI.  What crosses ranks per step: BatchNorm column sums
+(fp64, 2*g_l numbers per Residual block, forward and backward), the flat discriminator gradient
+buffer, the flat generator gradient buffer.  Parameters, optimiser state and the sampler tables are
+replicated; each rank draws its own batch shard from its own Philox streams, while the DP noise
+comes from a stream all ranks share, so it is added exactly once and replicas stay identical."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Dist(object):
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.active = self.world > 1
+        if self.active and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            if backend == 'nccl':
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def allreduce(self, t):
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def barrier(self):
+        if self.active:
+            dist.barrier()
+
+    def max_float(self, x, device):
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def shutdown(self):
+        if self.active and dist.is_initialized():
+            dist.destroy_process_group()

@@ -136,6 +136,15 @@ def test_philox_fills_and_noise_add(ops):
     e = torch.empty(n, device=dev())
     ops.fill(e, ops.FILL_EXP, rng, 5)
     assert abs(e.mean().item() - 1) < 5e-3 and e.min().item() > 0
+    # fp32 uniforms must stay strictly inside (0,1): -log(-log(u)) of the Gumbel draw is finite
+    # (regression: a 24-bit mapping rounded its top bucket to 1.0, ~4 hits in 2^26 draws)
+    uf = torch.empty(1 << 26, device=dev())
+    ops.fill(uf, ops.FILL_UNIFORM, rng, 9)
+    assert uf.min().item() > 0.0 and uf.max().item() < 1.0
+    ef = torch.empty(1 << 26, device=dev())
+    ops.fill(ef, ops.FILL_EXP, rng, 9)
+    assert ef.min().item() > 0.0 and torch.isfinite(ef).all()
+    del uf, ef
     u = torch.empty(n, dtype=torch.float64, device=dev())
     ops.fill(u, ops.FILL_UNIFORM64, rng, 6)
     assert 0 <= u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 2e-3
