@@ -51,45 +51,62 @@ struct Stage {
   static constexpr int LD = BMN + (KC ? 2 : 4);
   float4 r[PASSES];
 
-  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int mn0, int k0,
-                                       int MN, int Kend, bool vec) {
+  // Fast path (block-uniform choice, see `fast` below): straight-line 16-byte loads with no
+  // per-lane guard.  Rows/columns beyond the matrix edge are clamped to a valid address instead of
+  // zero-filled: they only feed accumulators whose outputs the epilogue never stores.  (Per-lane
+  // guarded loads make hipcc branch around every load and drain vmcnt at each join - a dependent
+  // L2 round trip per element.)
+  __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int mn0, int k0, int MN) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KC) {
+        int row = min(mn0 + p * 64 + (t >> 2), MN - 1);
+        r[p] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + 4 * (t & 3));
+      } else {
+        constexpr int TPR = BMN / 4;
+        constexpr int RPP = 256 / TPR;
+        int mn = min(mn0 + 4 * (t % TPR), ((MN + 3) & ~3) - 4);
+        r[p] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int mn0, int k0,
+                                       int MN, int Kend, bool fast) {
+    if (fast && k0 + BK <= Kend) {
+      load_fast(base, ld, mn0, k0, MN);
+      return;
+    }
+    // Edge / unaligned path: scalar loads from clamped (always valid) addresses, zeroed by select;
+    // still branch-free, so the loads stay in flight together.
+    const int t = threadIdx.x;
+    const int klast = Kend - 1, mlast = MN - 1;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      float e[4];
       if (KC) {
         int row = mn0 + p * 64 + (t >> 2);
         int k = k0 + 4 * (t & 3);
-        if (row < MN) {
-          const float* src = base + (int64_t)row * ld + k;
-          if (vec && k + 3 < Kend) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (k < Kend) v.x = src[0];
-            if (k + 1 < Kend) v.y = src[1];
-            if (k + 2 < Kend) v.z = src[2];
-            if (k + 3 < Kend) v.w = src[3];
-          }
+        const float* src = base + (int64_t)min(row, mlast) * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = src[min(k + j, klast)];
+          e[j] = (row <= mlast && k + j <= klast) ? v : 0.f;
         }
       } else {
         constexpr int TPR = BMN / 4;            // threads per k-row
         constexpr int RPP = 256 / TPR;          // k-rows per pass
-        int krow = p * RPP + t / TPR;
         int mn = mn0 + 4 * (t % TPR);
-        int k = k0 + krow;
-        if (k < Kend) {
-          const float* src = base + (int64_t)k * ld + mn;
-          if (vec && mn + 3 < MN) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (mn < MN) v.x = src[0];
-            if (mn + 1 < MN) v.y = src[1];
-            if (mn + 2 < MN) v.z = src[2];
-            if (mn + 3 < MN) v.w = src[3];
-          }
+        int k = k0 + p * RPP + t / TPR;
+        const float* src = base + (int64_t)min(k, klast) * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = src[min(mn + j, mlast)];
+          e[j] = (k <= klast && mn + j <= mlast) ? v : 0.f;
         }
       }
-      r[p] = v;
+      r[p] = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
 
@@ -114,7 +131,7 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, int PF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   using SA = Stage<BM, A_KC>;
   using SB = Stage<BN, B_KC>;
@@ -151,24 +168,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   const int64_t lda = A_KC ? g.a_rs : g.a_cs;
   const int64_t ldb = B_KC ? g.b_cs : g.b_rs;
-  SA sa;
-  SB sb;
+  // Register-staged prefetch ring, PF tiles deep: with only 1-2 resident blocks per CU (these GEMMs
+  // are small) nothing else hides the ~1 us L2/HBM latency, so the loads of tile t+PF are issued
+  // before the MFMAs of tile t and land in LDS PF-1 iterations later.
+  // 16-byte-aligned operand, and an edge tile (if any) that may be clamped: always for a
+  // k-contiguous operand (row clamp); for an m/n-contiguous one only if the rows are long enough
+  // (ld >= extent rounded up to 4) for the last 16-byte load to stay inside its row
+  const bool fa = g.a_vec && (A_KC ? g.M >= 1 : (m0 + BM <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
+  const bool fb = g.b_vec && (B_KC ? g.N >= 1 : (n0 + BN <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
+  SA sa[PF];
+  SB sb[PF];
   const int ntile = (k_end - k_begin + BK - 1) / BK;
-  if (ntile > 0) {
-    sa.load(g.A, lda, m0, k_begin, g.M, k_end, g.a_vec);
-    sb.load(g.B, ldb, n0, k_begin, g.N, k_end, g.b_vec);
-    sa.store(As);
-    sb.store(Bs);
-  }
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntile) {
-      sa.load(g.A, lda, m0, k_begin + (t + 1) * BK, g.M, k_end, g.a_vec);
-      sb.load(g.B, ldb, n0, k_begin + (t + 1) * BK, g.N, k_end, g.b_vec);
-    }
-    const float* as = As + cur * BK * LDA;
-    const float* bs = Bs + cur * BK * LDB;
+  const int nfull = (fa && fb) ? (k_end - k_begin) / BK : 0;
+  const int nmain = (nfull / PF) * PF;
+
+  auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -182,10 +196,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < ntile) {
-      sa.store(As + (cur ^ 1) * BK * LDA);
-      sb.store(Bs + (cur ^ 1) * BK * LDB);
+  };
+
+  // Main pipeline: nmain full K-tiles, strictly branch-free inside (loads past the end are clamped
+  // to the last tile, stores are unconditional), so hipcc keeps PF-1 tiles of loads in flight with
+  // counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow join.
+  if (nmain > 0) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M);
+      sb[j].load_fast(g.B, ldb, n0, k_begin + j * BK, g.N);
     }
+    sa[0].store(As);
+    sb[0].store(Bs);
+    __syncthreads();
+    for (int t0 = 0; t0 < nmain; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int cur = u & 1;              // PF is even, so t & 1 == u & 1
+        const int tl = min(t0 + u + PF, nmain - 1);
+        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M);
+        sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
+        compute(As + cur * BK * LDA, Bs + cur * BK * LDB);
+        sa[(u + 1) % PF].store(As + (cur ^ 1) * BK * LDA);
+        sb[(u + 1) % PF].store(Bs + (cur ^ 1) * BK * LDB);
+        __syncthreads();
+      }
+    }
+  }
+  // Remainder (< PF full tiles, a partial last tile, or operands the fast path cannot take).
+  for (int t = nmain; t < ntile; ++t) {
+    sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa);
+    sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
+    sa[0].store(As);
+    sb[0].store(Bs);
+    __syncthreads();
+    compute(As, Bs);
     __syncthreads();
   }
 
@@ -229,13 +275,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-template <int BM, int BN>
+// Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
+__global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
+  int64_t total = (int64_t)g.M * g.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int row = (int)(i / g.N), col = (int)(i - (int64_t)row * g.N);
+    float* cp = g.C + (int64_t)row * g.ldc + col;
+    float v = *cp + (g.bias ? g.bias[col] : 0.f);
+    if (g.epi == EPI_LEAKY_DROPOUT) {
+      float keep;
+      if (g.keep) keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+      else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
+      float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
+      g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+      v *= slope;
+    } else if (g.epi == EPI_MUL) {
+      v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+    } else if (g.epi == EPI_RELU) {
+      v = fmaxf(v, 0.f);
+    }
+    *cp = v;
+  }
+}
+
+static int g_force_tile = 0;
+// Tuning / test hook: force the block tile (64 or 128; 0 = automatic choice).
+extern "C" int dpc_gemm_config(int force_tile) {
+  if (force_tile != 0 && force_tile != 64 && force_tile != 128) return DPC_EINVAL;
+  g_force_tile = force_tile;
+  return DPC_OK;
+}
+
+template <int BM, int BN, int PF>
 static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(256);
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
-  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, PF>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, PF>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF>), grid, block, 0, st, g);
 }
 
 extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
@@ -265,17 +342,19 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
   g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-  // Tile choice: 128x128 only when it still yields at least one block per CU.
+  // Tile choice: 128x128 only when it still yields at least two blocks per CU.
   int64_t big = dpc_cdiv(M, 128) * dpc_cdiv(N, 128);
-  bool use_big = big >= 256;
+  bool use_big = g_force_tile ? g_force_tile == 128 : big >= 512;
   int bm = use_big ? 128 : 64;
   g.tiles_m = (int)dpc_cdiv(M, bm);
   g.tiles_n = (int)dpc_cdiv(N, bm);
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
+  bool deferred_epi = false;
   if (splitk <= 0) {
-    // auto: split only plain accumulating products with a long K and too few tiles to fill the chip
+    // auto: split a long K when there are too few tiles to fill the chip.  Products with a bias /
+    // activation epilogue then run as plain split-K sums + one elementwise pass (beta must be 0).
     splitk = 1;
-    if (epi == EPI_NONE && (beta == 0.f || beta == 1.f) && blocks < 128 && K >= 1024) {
+    if ((beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && blocks < 128 && K >= 1024) {
       int64_t s = dpc_cdiv(256, blocks);
       int64_t maxs = K / 256;
       if (s > maxs) s = maxs;
@@ -283,7 +362,11 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       if (s >= 2) splitk = (int)s;
     }
   }
-  DPC_CHECK_ARG(splitk == 1 || (epi == EPI_NONE && (beta == 0.f || beta == 1.f)), "gemm: split-K needs a plain epilogue and beta in {0,1}");
+  if (splitk > 1 && (epi != EPI_NONE || bias)) {
+    DPC_CHECK_ARG(beta == 0.f, "gemm: split-K with an epilogue needs beta == 0");
+    deferred_epi = true;
+  }
+  DPC_CHECK_ARG(splitk == 1 || beta == 0.f || beta == 1.f, "gemm: split-K needs beta in {0,1}");
   g.splitk = splitk;
   int ktiles = (int)dpc_cdiv(K, BK);
   g.kchunk = (int)dpc_cdiv(ktiles, splitk) * BK;
@@ -293,8 +376,12 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
     g.beta = 1.f;   // accumulate into the zeroed C
   }
-  if (use_big) launch_tile<128, 128>(g, a_kc, b_kc, st);
-  else launch_tile<64, 64>(g, a_kc, b_kc, st);
+  GemmArgs full = g;
+  if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; }
+  if (use_big) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
+  else launch_tile<64, 64, 4>(g, a_kc, b_kc, st);
+  if (deferred_epi)
+    hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(dpc_grid((int64_t)M * N, 256)), dim3(256), 0, st, full);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

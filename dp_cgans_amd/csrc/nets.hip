@@ -60,10 +60,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColArgs a) {
 }
 
 static int pick_R(int64_t rows, int F, int max_R) {
-  // enough row chunks to spread the reduction over the chip, at least 64 rows per chunk
+  // enough row chunks to spread the reduction over the chip, at least 256 rows per chunk; the
+  // finish kernel walks the chunks serially, so keep them few
   int64_t colblocks = dpc_cdiv(F, 64);
-  int64_t R = dpc_cdiv(1024, colblocks);
-  int64_t cap = dpc_cdiv(rows, 64);
+  int64_t R = dpc_cdiv(256, colblocks);
+  if (R > 32) R = 32;
+  int64_t cap = dpc_cdiv(rows, 256);
   if (R > cap) R = cap;
   if (R > max_R) R = max_R;
   if (R < 1) R = 1;

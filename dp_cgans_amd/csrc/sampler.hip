@@ -266,26 +266,37 @@ extern "C" int dpc_row_gather(const float* table, int64_t ld, const int64_t* row
 }
 
 // Uniform random permutation of 0..B-1 by ranking 64-bit Philox keys (ties broken by index).
-__global__ __launch_bounds__(256) void perm_keys_kernel(const uint64_t* rng, uint32_t site, int64_t B, uint64_t* keys) {
+__global__ __launch_bounds__(256) void perm_keys_kernel(const uint64_t* rng, uint32_t site, int64_t B, uint64_t* keys,
+                                                        unsigned long long* ranks) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) keys[i] = ((uint64_t)dpc_draw_u32(rng, site, 2 * (uint64_t)i) << 32) | dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1);
-}
-__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* __restrict__ keys, int64_t B, int64_t* perm) {
-  __shared__ uint64_t tile[256];
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t ki = i < B ? keys[i] : 0;
-  int64_t rank = 0;
-  for (int64_t t0 = 0; t0 < B; t0 += 256) {
-    __syncthreads();
-    tile[threadIdx.x] = (t0 + threadIdx.x < B) ? keys[t0 + threadIdx.x] : ~0ull;
-    __syncthreads();
-    int lim = (int)min((int64_t)256, B - t0);
-    for (int j = 0; j < lim; ++j) {
-      uint64_t kj = tile[j];
-      rank += (kj < ki) || (kj == ki && (t0 + j) < i);
-    }
+  if (i < B) {
+    keys[i] = ((uint64_t)dpc_draw_u32(rng, site, 2 * (uint64_t)i) << 32) | dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1);
+    ranks[i] = 0;
   }
-  if (i < B) perm[rank] = i;
+}
+// grid (ceil(B/256), ceil(B/1024)): block (x, y) counts, for its 256 keys, how many of the y-th
+// 1024 keys sort before them; integer atomics, so the result does not depend on arrival order.
+__global__ __launch_bounds__(256) void perm_count_kernel(const uint64_t* __restrict__ keys, int64_t B,
+                                                         unsigned long long* __restrict__ ranks) {
+  __shared__ uint64_t tile[1024];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j0 = (int64_t)blockIdx.y * 1024;
+  for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < B) ? keys[j0 + q] : ~0ull;
+  __syncthreads();
+  if (i >= B) return;
+  uint64_t ki = keys[i];
+  int lim = (int)min((int64_t)1024, B - j0);
+  unsigned cnt = 0;
+  for (int j = 0; j < lim; ++j) {
+    uint64_t kj = tile[j];
+    cnt += (kj < ki) || (kj == ki && (j0 + j) < i);
+  }
+  if (cnt) atomicAdd(&ranks[i], (unsigned long long)cnt);
+}
+__global__ __launch_bounds__(256) void perm_scatter_kernel(const unsigned long long* __restrict__ ranks, int64_t B,
+                                                           int64_t* __restrict__ perm) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) perm[ranks[i]] = i;
 }
 
 extern "C" int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
@@ -293,9 +304,11 @@ extern "C" int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, in
   DPC_CHECK_ARG(rng && perm && keys_ws && B >= 0, "random_perm: bad argument");
   if (B == 0) return DPC_OK;
   hipStream_t st = (hipStream_t)stream;
-  unsigned grid = (unsigned)dpc_cdiv(B, 256);
-  hipLaunchKernelGGL(perm_keys_kernel, dim3(grid), dim3(256), 0, st, rng, site, B, keys_ws);
-  hipLaunchKernelGGL(perm_rank_kernel, dim3(grid), dim3(256), 0, st, keys_ws, B, perm);
+  unsigned gx = (unsigned)dpc_cdiv(B, 256), gy = (unsigned)dpc_cdiv(B, 1024);
+  unsigned long long* ranks = (unsigned long long*)(keys_ws + B);
+  hipLaunchKernelGGL(perm_keys_kernel, dim3(gx), dim3(256), 0, st, rng, site, B, keys_ws, ranks);
+  hipLaunchKernelGGL(perm_count_kernel, dim3(gx, gy), dim3(256), 0, st, keys_ws, B, ranks);
+  hipLaunchKernelGGL(perm_scatter_kernel, dim3(gx), dim3(256), 0, st, ranks, B, perm);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -159,8 +159,9 @@ class StepEngine(object):
         self.dZ = [torch.zeros(B, w, **f32) for w in self.gdim]
         self.bn_mean = [torch.zeros(w, **f32) for w in self.gdim]
         self.bn_invstd = [torch.zeros(w, **f32) for w in self.gdim]
-        self.fake = torch.zeros(B, self.Dd, **f32)
-        self.dfake = torch.zeros(B, self.Dd, **f32)
+        ldd = (self.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
+        self.fake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
+        self.dfake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
         self.Xd = torch.zeros(3 * B, self.row, **f32)
         self.Xd3 = self.Xd.view(3 * n, self.K0)
         self.dX = torch.zeros(B, self.row, **f32)
@@ -187,7 +188,7 @@ class StepEngine(object):
         self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
         self.gcount = torch.zeros(B, device=d, dtype=torch.int64)
         self.perm = torch.zeros(B, device=d, dtype=torch.int64)
-        self.keys_ws = torch.zeros(B, device=d, dtype=torch.int64)
+        self.keys_ws = torch.zeros(2 * B, device=d, dtype=torch.int64)
         self.row_id = torch.zeros(B, device=d, dtype=torch.int64)
         self.hook_add = torch.zeros(len(self.disc.keys), **f32)
         # per-rank streams for the batch shard (z, gumbel, dropout, sampling); one stream shared by all

@@ -58,6 +58,9 @@ int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep, const uint64_t* rng,
                  uint32_t site, float leak, int splitk, void* stream);
 
+/* tuning / test hook: force the GEMM block tile (64, 128; 0 = automatic).  Host-side state. */
+int dpc_gemm_config(int force_tile);
+
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
 /* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)
  * from exp_noise[b*ld_noise + col] or Philox idx b*Dd + col. */
@@ -104,7 +107,7 @@ int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const
 int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd,
                    float* out, int64_t ldo, const int32_t* sel, const int64_t* perm, int C,
                    void* stream);
-/* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution; keys_ws: B uint64. */
+/* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution; keys_ws: 2*B uint64. */
 int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
                     void* stream);
 

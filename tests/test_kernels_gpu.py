@@ -361,7 +361,7 @@ def test_sampler_philox_draws_are_valid_and_distributed(ops):
     assert 0 <= pid.min().item() and pid.max().item() < nd * (nd - 1) // 2
     assert len(torch.unique(pid)) == nd * (nd - 1) // 2          # every pair shows up at B = 8192
     perm = torch.empty(B, dtype=torch.int64, device=dev())
-    keys = torch.empty(B, dtype=torch.int64, device=dev())
+    keys = torch.empty(2 * B, dtype=torch.int64, device=dev())
     ops.random_perm(rng, perm, keys)
     assert torch.equal(torch.sort(perm).values, torch.arange(B, device=dev()))
     row_id = torch.empty(B, dtype=torch.int64, device=dev())
