@@ -1,0 +1,150 @@
+// DP-SGD pieces of the discriminator update (north_star; no counterpart in the reference, whose
+// private=True is the grad-hook noise of dp_cgan.py:638-647 - that one is dpc_hook_noise below).
+//
+// An example is one pac group i.  Its loss  l_i = D(fake_i) - D(real_i) + lambda (||grad D(xhat_i)|| - 1)^2
+// touches three rows of the stacked discriminator batch: i (fake), n+i (real), 2n+i (penalty).  For
+// a layer with weight W the example's gradient is the sum of three outer products
+//     G_i = sum_p  delta[p*n+i]^T  act[p*n+i]          p = 0,1,2
+// (for the penalty row delta = u-chain, act = v-chain), so
+//     ||G_i||_F^2 = sum_{p,q} (delta_p . delta_q)(act_p . act_q)
+// i.e. two 3x3 Gram matrices per example and layer: the per-example gradient is never formed
+// ("ghost norm").  Bias gradient of the example: delta_0 + delta_1 (the penalty has none).
+// HBM-bound: every delta / act element is read once, 4*(3n)*(d + K) bytes per layer.
+#include "dpc_common.h"
+
+struct GramArgs {
+  const float* delta; int64_t ldd; int d;
+  const float* act; int64_t lda; int K;
+  int64_t n; int with_bias; int accumulate;
+  double* norm2;
+};
+
+// 6 unique entries of the symmetric 3x3 Gram of rows r0, r1, r2 (each `len` long): this thread's
+// strided share.  VEC: 16-byte loads (rows 16-byte aligned, len % 4 == 0).
+template <bool VEC>
+__device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, const float* __restrict__ r1,
+                                              const float* __restrict__ r2, int len, float g[6]) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) g[q] = 0.f;
+  if (VEC) {
+    const float4* a = reinterpret_cast<const float4*>(r0);
+    const float4* b = reinterpret_cast<const float4*>(r1);
+    const float4* c = reinterpret_cast<const float4*>(r2);
+    for (int j = threadIdx.x; j < (len >> 2); j += blockDim.x) {
+      float4 x = a[j], y = b[j], z = c[j];
+      g[0] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      g[1] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      g[2] += x.x * z.x + x.y * z.y + x.z * z.z + x.w * z.w;
+      g[3] += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      g[4] += y.x * z.x + y.y * z.y + y.z * z.z + y.w * z.w;
+      g[5] += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+    }
+  } else {
+    for (int j = threadIdx.x; j < len; j += blockDim.x) {
+      float x = r0[j], y = r1[j], z = r2[j];
+      g[0] += x * x; g[1] += x * y; g[2] += x * z; g[3] += y * y; g[4] += y * z; g[5] += z * z;
+    }
+  }
+}
+
+template <bool VEC_D, bool VEC_A>
+__global__ __launch_bounds__(256) void persample_gram_kernel(GramArgs a) {
+  __shared__ double red[4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+    float g[12];
+    gram3_partial<VEC_D>(a.delta + i * a.ldd, a.delta + (a.n + i) * a.ldd, a.delta + (2 * a.n + i) * a.ldd, a.d, g);
+    gram3_partial<VEC_A>(a.act + i * a.lda, a.act + (a.n + i) * a.lda, a.act + (2 * a.n + i) * a.lda, a.K, g + 6);
+    // wavefront-level reduction of the 12 partial dot products, then 4 waves through LDS
+    double s[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) s[q] = dpc_wave_sum((double)g[q]);
+    __syncthreads();                       // red[] of the previous example has been consumed
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) red[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+      // sum_pq (D D^T)_pq (A A^T)_pq, off-diagonal entries twice
+      double v = t[0] * t[6] + t[3] * t[9] + t[5] * t[11] + 2.0 * (t[1] * t[7] + t[2] * t[8] + t[4] * t[10]);
+      if (a.with_bias) v += t[0] + 2.0 * t[1] + t[3];       // ||delta_0 + delta_1||^2
+      a.norm2[i] = a.accumulate ? a.norm2[i] + v : v;
+    }
+  }
+}
+
+// norm2[i] (+)= squared Frobenius norm of example i's gradient of one Linear layer (weight, and
+// bias when with_bias).  delta [3n, d], act [3n, K]; rows i, n+i, 2n+i belong to example i.
+extern "C" int dpc_persample_gram(const float* delta, int64_t ldd, int d, const float* act, int64_t lda, int K,
+                                  int64_t n, int with_bias, int accumulate, double* norm2, void* stream) {
+  DPC_CHECK_ARG(delta && act && norm2, "persample_gram: null pointer");
+  DPC_CHECK_ARG(n > 0 && d > 0 && K > 0 && ldd >= d && lda >= K, "persample_gram: bad shape");
+  GramArgs a;
+  a.delta = delta; a.ldd = ldd; a.d = d; a.act = act; a.lda = lda; a.K = K; a.n = n; a.with_bias = with_bias;
+  a.accumulate = accumulate; a.norm2 = norm2;
+  bool vd = (((uintptr_t)delta & 15) == 0) && (ldd % 4 == 0) && (d % 4 == 0);
+  bool va = (((uintptr_t)act & 15) == 0) && (lda % 4 == 0) && (K % 4 == 0);
+  dim3 grid((unsigned)(n < 16384 ? n : 16384)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (vd && va) hipLaunchKernelGGL((persample_gram_kernel<true, true>), grid, block, 0, st, a);
+  else if (vd) hipLaunchKernelGGL((persample_gram_kernel<true, false>), grid, block, 0, st, a);
+  else if (va) hipLaunchKernelGGL((persample_gram_kernel<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((persample_gram_kernel<false, false>), grid, block, 0, st, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// c_i = min(1, clip / (gscale * sqrt(norm2[i]))); rowc[p*n + i] = c_i for the three rows of example i
+// (the per-row scale handed to the weight-gradient GEMM and the bias column sums), and
+// rowc_w[r] = rowc[r] * roww[r] (the head layer's row weights).  norm_out[i] = gscale*sqrt(norm2[i]).
+__global__ __launch_bounds__(256) void clip_factors_kernel(const double* __restrict__ norm2, int64_t n, float clip,
+                                                           float gscale, float* __restrict__ rowc,
+                                                           const float* __restrict__ roww,
+                                                           float* __restrict__ rowc_w, float* __restrict__ norm_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float nrm = gscale * (float)sqrt(norm2[i]);
+    float c = nrm > clip ? clip / nrm : 1.f;
+    if (norm_out) norm_out[i] = nrm;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      rowc[p * n + i] = c;
+      if (rowc_w) rowc_w[p * n + i] = c * roww[p * n + i];
+    }
+  }
+}
+
+extern "C" int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,
+                                const float* roww, float* rowc_w, float* norm_out, void* stream) {
+  DPC_CHECK_ARG(norm2 && rowc && n > 0, "clip_factors: bad argument");
+  DPC_CHECK_ARG(clip > 0.f && gscale > 0.f, "clip_factors: clip bound and scale must be positive");
+  DPC_CHECK_ARG(!rowc_w || roww, "clip_factors: row weights missing");
+  hipLaunchKernelGGL(clip_factors_kernel, dim3(dpc_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, norm2, n, clip,
+                     gscale, rowc, roww, rowc_w, norm_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// The reference's private-mode hook noise (dp_cgan.py:638-647): every hook firing adds
+// one scalar N(0,1)/B to the whole gradient tensor, and after t discriminator steps a tensor
+// carries t+1 hook sets, each fired `fires[s]` times per step.  The sum of those independent
+// scalars is N(0, fires[s]*(t+1)) / B:  seg_add[s] = z_s * sqrt(fires[s] * (t+1)) * inv_B.
+__global__ void hook_noise_kernel(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
+                                  const uint64_t* rng, uint32_t site) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  float t1 = (float)(t_dev[0] + 1);
+  seg_add[s] = dpc_draw_normal(rng, site, (uint64_t)s) * sqrtf(fires[s] * t1) * inv_B;
+}
+
+extern "C" int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
+                              const uint64_t* rng, uint32_t site, void* stream) {
+  DPC_CHECK_ARG(seg_add && fires && t_dev && rng && nseg > 0, "hook_noise: bad argument");
+  hipLaunchKernelGGL(hook_noise_kernel, dim3((unsigned)dpc_cdiv(nseg, 64)), dim3(64), 0, (hipStream_t)stream, seg_add,
+                     nseg, fires, t_dev, inv_B, rng, site);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

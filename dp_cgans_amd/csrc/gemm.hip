@@ -39,24 +39,27 @@ struct GemmArgs {
   int splitk, kchunk;
   int tiles_m, tiles_n;
   int a_vec, b_vec;
+  const float* kscale;   // optional: A(m,k) *= kscale[k] (fused clip-scale-sum; m-contiguous A only)
 };
 
 constexpr int BK = 16;
 
-template <int BMN, bool KC>
+template <int BMN, bool KC, bool KS = false>
 struct Stage {
   // KC: operand is k-contiguous in global memory (stride_mn = leading dimension, stride_k = 1).
   // !KC: operand is m/n-contiguous (stride_k = leading dimension).
   static constexpr int PASSES = BMN / 64;
   static constexpr int LD = BMN + (KC ? 2 : 4);
   float4 r[PASSES];
+  float sc[KS ? PASSES : 1];   // per-k scale of this thread's k-row (KS: m/n-contiguous operand only)
 
   // Fast path (block-uniform choice, see `fast` below): straight-line 16-byte loads with no
   // per-lane guard.  Rows/columns beyond the matrix edge are clamped to a valid address instead of
   // zero-filled: they only feed accumulators whose outputs the epilogue never stores.  (Per-lane
   // guarded loads make hipcc branch around every load and drain vmcnt at each join - a dependent
   // L2 round trip per element.)
-  __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int mn0, int k0, int MN) {
+  __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int mn0, int k0, int MN,
+                                            const float* __restrict__ ks = nullptr) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
@@ -68,14 +71,15 @@ struct Stage {
         constexpr int RPP = 256 / TPR;
         int mn = min(mn0 + 4 * (t % TPR), ((MN + 3) & ~3) - 4);
         r[p] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
+        if (KS) sc[p] = ks[k0 + p * RPP + t / TPR];
       }
     }
   }
 
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int mn0, int k0,
-                                       int MN, int Kend, bool fast) {
+                                       int MN, int Kend, bool fast, const float* __restrict__ ks = nullptr) {
     if (fast && k0 + BK <= Kend) {
-      load_fast(base, ld, mn0, k0, MN);
+      load_fast(base, ld, mn0, k0, MN, ks);
       return;
     }
     // Edge / unaligned path: scalar loads from clamped (always valid) addresses, zeroed by select;
@@ -105,6 +109,7 @@ struct Stage {
           float v = src[min(mn + j, mlast)];
           e[j] = (k <= klast && mn + j <= mlast) ? v : 0.f;
         }
+        if (KS) sc[p] = ks[min(k, klast)];
       }
       r[p] = make_float4(e[0], e[1], e[2], e[3]);
     }
@@ -125,15 +130,18 @@ struct Stage {
         constexpr int TPR = BMN / 4;
         constexpr int RPP = 256 / TPR;
         int krow = p * RPP + t / TPR;
-        *reinterpret_cast<float4*>(&s[krow * LD + 4 * (t % TPR)]) = r[p];
+        float4 v = r[p];
+        if (KS) { v.x *= sc[p]; v.y *= sc[p]; v.z *= sc[p]; v.w *= sc[p]; }
+        *reinterpret_cast<float4*>(&s[krow * LD + 4 * (t % TPR)]) = v;
       }
     }
   }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int PF>
+template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  using SA = Stage<BM, A_KC>;
+  static_assert(!(KS && A_KC), "kscale needs an m-contiguous A");
+  using SA = Stage<BM, A_KC, KS>;
   using SB = Stage<BN, B_KC>;
   constexpr int LDA = SA::LD, LDB = SB::LD;
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   if (nmain > 0) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M);
+      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M, g.kscale);
       sb[j].load_fast(g.B, ldb, n0, k_begin + j * BK, g.N);
     }
     sa[0].store(As);
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       for (int u = 0; u < PF; ++u) {
         const int cur = u & 1;              // PF is even, so t & 1 == u & 1
         const int tl = min(t0 + u + PF, nmain - 1);
-        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M);
+        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
         sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
         compute(As + cur * BK * LDA, Bs + cur * BK * LDB);
         sa[(u + 1) % PF].store(As + (cur ^ 1) * BK * LDA);
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
   // Remainder (< PF full tiles, a partial last tile, or operands the fast path cannot take).
   for (int t = nmain; t < ntile; ++t) {
-    sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa);
+    sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
     sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
     sa[0].store(As);
     sb[0].store(Bs);
@@ -309,6 +317,11 @@ extern "C" int dpc_gemm_config(int force_tile) {
 template <int BM, int BN, int PF>
 static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(256);
+  if (g.kscale) {     // validated by the caller: A is m-contiguous
+    if (b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF, true>), grid, block, 0, st, g);
+    return;
+  }
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, PF>), grid, block, 0, st, g);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, PF>), grid, block, 0, st, g);
   else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF>), grid, block, 0, st, g);
@@ -319,7 +332,8 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
                             const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
                             const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
                             const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
-                            const uint64_t* rng, uint32_t site, float leak, int splitk, void* stream) {
+                            const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
+                            void* stream) {
   DPC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return DPC_OK;
   DPC_CHECK_ARG(A && B && C, "gemm: null operand");
@@ -339,6 +353,8 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   g.keep = keep; g.ld_keep = ld_keep; g.rng = rng; g.site = site; g.leak = leak;
   // k-contiguous when the k stride is 1 (ties, e.g. K == 1, go to the k-contiguous path)
   bool a_kc = (a_cs == 1), b_kc = (b_rs == 1);
+  DPC_CHECK_ARG(!kscale || !a_kc, "gemm: kscale needs an m-contiguous A (the weight-gradient product)");
+  g.kscale = kscale;
   int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
   g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;

@@ -103,7 +103,8 @@ class NoDist(object):
 class StepEngine(object):
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
-                 private=False, seed=0, dist=None, global_batch=None):
+                 private=False, seed=0, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
+                 weight_clip=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
         spans, cols, col2d, col2c = span_tables(span_info)
@@ -118,6 +119,17 @@ class StepEngine(object):
         self.gn = self.gB // pac
         self.gdim, self.ddim = list(generator_dim), list(discriminator_dim)
         self.private = private
+        if dp_mode not in ('reference', 'dpsgd'):
+            raise ValueError("dp_mode must be 'reference' or 'dpsgd'")
+        # private=True, dp_mode 'reference': the reference's grad-hook noise + weight clamp +-0.01
+        # (dp_cgan.py:638-661).  dp_mode 'dpsgd': per-example (pac group) clipping to dp_clip and one
+        # N(0, (dp_sigma*dp_clip)^2) add to the summed gradient; weight clamp only if weight_clip is given.
+        self.dp_mode = dp_mode if private else 'off'
+        self.dp_sigma, self.dp_clip = float(dp_sigma), float(dp_clip)
+        if weight_clip is None:
+            weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
+        self.weight_clip = float(weight_clip)
+        self._ar_hook = None
         self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
         d = self.dev
         self.spans = torch.from_numpy(spans).to(d)
@@ -191,11 +203,17 @@ class StepEngine(object):
         self.keys_ws = torch.zeros(2 * B, device=d, dtype=torch.int64)
         self.row_id = torch.zeros(B, device=d, dtype=torch.int64)
         self.hook_add = torch.zeros(len(self.disc.keys), **f32)
+        # both backward passes (penalty, loss_d) fire every hook except the last bias's, which only
+        # loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
+        self.hook_fires = torch.tensor([2.0] * (len(self.disc.keys) - 1) + [1.0], **f32)
+        self.norm2 = torch.zeros(n, device=d, dtype=torch.float64)      # DP-SGD: per-example squared gradient norms
+        self.norms = torch.zeros(n, **f32)
+        self.rowc = torch.ones(3 * n, **f32)                              # clip factor of each stacked row
+        self.rowc_w = torch.zeros(3 * n, **f32)                           # ... times rowscale_d
         # per-rank streams for the batch shard (z, gumbel, dropout, sampling); one stream shared by all
         # ranks for the DP noise, so that it is added exactly once and replicas stay bit-identical
         self.rng = ops.new_rng(seed + 7919 * self.dist.rank, d)
         self.rng_shared = ops.new_rng(seed ^ 0x3c3c3c3c, d)
-        self.d_steps_done = 0
         self.sampler = None      # DeviceSampler, attached by the caller
 
     # ------------------------------------------------------------------------------------------
@@ -286,7 +304,7 @@ class StepEngine(object):
             ops.gemm(x, g.P('seq.%d.fc.weight' % l), self.Z[l], trans_b=True, bias=g.P('seq.%d.fc.bias' % l))
             R = ops.colreduce_partial(0, self.Z[l], self.part)
             nel = R * 2 * self.gdim[l]
-            self.dist.allreduce(self.part[:nel])
+            self._allreduce(self.part[:nel])
             ops.colreduce_finish(self.part, R, 2, self.gdim[l], 0, self.bn_mean[l], self.bn_invstd[l], count=count,
                                  run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
                                  run_var=self.bn_run['seq.%d.bn.running_var' % l])
@@ -323,6 +341,14 @@ class StepEngine(object):
             ops.gemm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
                      aux_in=self.S[i - 1][0:rows])
 
+    def _allreduce(self, t):
+        if self.dist.world == 1:
+            return t
+        if self._ar_hook is not None:      # graph capture in progress: the collective runs between graph segments
+            self._ar_hook(t)
+            return t
+        return self.dist.allreduce(t)
+
     def _colsum(self, x, out, w=None, accumulate=False):
         R = ops.colreduce_partial(1, x, self.part, w=w)
         ops.colreduce_finish(self.part, R, 1, x.shape[1], 1, out, accumulate=accumulate)
@@ -347,41 +373,57 @@ class StepEngine(object):
         ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
         ops.gp_norm(self.Xd3[gp_rows], 2.0 * GP_LAMBDA / self.gn, self.pen_rows)    # -> v0 in place
         ops.sum_f64(self.pen_rows, GP_LAMBDA / self.gn, self.losses[1:2])
+        # penalty v-chain first, so that every layer's (delta, input) pair exists before the DP clip
+        # factors: v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
         prev = self.Xd3
         for i in range(M):
-            Wi = d.P('seq.%d.weight' % (3 * i))
-            ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True)      # loss + penalty in one product
-            self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1))
-            # v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
-            ops.gemm(prev[gp_rows], Wi, self.H[i][gp_rows], trans_b=True, epi=ops.EPI_MUL, aux_in=self.S[i][gp_rows])
+            ops.gemm(prev[gp_rows], d.P('seq.%d.weight' % (3 * i)), self.H[i][gp_rows], trans_b=True, epi=ops.EPI_MUL,
+                     aux_in=self.S[i][gp_rows])
             prev = self.H[i]
-        self._colsum(prev, d.G('seq.%d.weight' % (3 * M)), w=self.rowscale_d)
-        self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=self.rowscale_d[0:2 * n])
+        kscale, w_last, w_bias = None, self.rowscale_d, None
+        if self.dp_mode == 'dpsgd':
+            # per-example gradient norms (ghost norm over the 3 rows of each pac group), clip factors
+            prev = self.Xd3
+            for i in range(M):
+                ops.persample_gram(self.Dl[i], prev, n, self.norm2, with_bias=True, accumulate=i > 0)
+                prev = self.H[i]
+            ops.persample_gram(self.rowscale_d.view(-1, 1), prev, n, self.norm2, with_bias=True, accumulate=True)
+            ops.clip_factors(self.norm2, self.dp_clip, float(self.gn), self.rowc, roww=self.rowscale_d,
+                             rowc_w=self.rowc_w, norm_out=self.norms)
+            kscale, w_last, w_bias = self.rowc, self.rowc_w, self.rowc[0:2 * n]
+        prev = self.Xd3
+        for i in range(M):
+            # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
+            ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
+            self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1), w=w_bias)
+            prev = self.H[i]
+        self._colsum(prev, d.G('seq.%d.weight' % (3 * M)), w=w_last)
+        self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=w_last[0:2 * n])
         if update:
             self._disc_update(inj)
         ops.state_advance(self.rng)
 
     def _disc_update(self, inj):
         d = self.disc
-        self.dist.allreduce(d.g)
-        seg_add = None
-        if self.private:
+        self._allreduce(d.g)
+        seg_add, seg_off, noise_scale, noise_inj = None, None, 0.0, None
+        if self.dp_mode == 'reference':
             # reference behaviour (dp_cgan.py:638-647): one scalar N(0,1)/B per parameter
-            # tensor and hook firing; after t discriminator steps each tensor carries t hooks.
+            # tensor and hook firing; after t discriminator steps each tensor carries t+1 hook sets.
             if 'hook_noise' in inj:
                 self.hook_add.copy_(inj['hook_noise'])
             else:
-                # both backward passes (penalty, loss_d) fire every hook except the last bias's, which
-                # only loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
-                fires = np.array([2.0] * (len(d.keys) - 1) + [1.0])
-                std = np.sqrt(fires * (self.d_steps_done + 1)) / self.gB
-                ops.fill(self.hook_add, ops.FILL_NORMAL, self.rng_shared, ops.SITE_HOOK, 0.0, 1.0)
-                self.hook_add.mul_(torch.from_numpy(std.astype(np.float32)).to(self.dev))
-            seg_add = self.hook_add
-        ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=0.01 if self.private else 0.0, t_dev=d.t,
-                      seg_off=d.seg_off if seg_add is not None else None, seg_add=seg_add)
+                ops.hook_noise(self.hook_add, self.hook_fires, d.t, 1.0 / self.gB, self.rng_shared)
+            seg_add, seg_off = self.hook_add, d.seg_off
+        elif self.dp_mode == 'dpsgd':
+            # the gradient buffer holds (1/n) sum_i clip(g_i); one N(0, (sigma*C)^2) draw per
+            # parameter from the stream all ranks share, scaled by the same 1/n
+            noise_scale = self.dp_sigma * self.dp_clip / self.gn
+            noise_inj = inj.get('dp_noise')
+        ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=self.weight_clip if self.private else 0.0,
+                      t_dev=d.t, seg_off=seg_off, seg_add=seg_add, noise_scale=noise_scale, noise_inj=noise_inj,
+                      rng=self.rng_shared, site=ops.SITE_NOISE_D)
         ops.state_advance(self.rng_shared, t_a=d.t)
-        self.d_steps_done += 1
 
     # ------------------------------------------------------------------------------------------
     # generator update
@@ -415,7 +457,7 @@ class StepEngine(object):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], self.Hg[:, blk]
             R = ops.colreduce_partial(2, dy, self.part, y=yv, z=self.Z[l], mean=self.bn_mean[l], invstd=self.bn_invstd[l])
-            self.dist.allreduce(self.part[:R * 2 * self.gdim[l]])
+            self._allreduce(self.part[:R * 2 * self.gdim[l]])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
             ops.colreduce_finish(self.part, R, 2, self.gdim[l], 2, dbeta, dgamma)
             ops.bn_relu_bwd(dy, yv, self.Z[l], self.bn_mean[l], self.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
@@ -438,7 +480,7 @@ class StepEngine(object):
             for l in range(self.L):
                 g.G('seq.%d.bn.weight' % l).mul_(1.0 / self.dist.world)
                 g.G('seq.%d.bn.bias' % l).mul_(1.0 / self.dist.world)
-        self.dist.allreduce(g.g)
+        self._allreduce(g.g)
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
         ops.state_advance(t_a=g.t)
 
@@ -455,3 +497,70 @@ class StepEngine(object):
         ops.apply_activate_fwd(self.fake, out, self.spans, rng=self.rng)
         ops.state_advance(self.rng)
         return out
+
+
+class GraphStep(object):
+    """One training step (``d_steps`` discriminator updates + one generator update) replayed as HIP
+    graphs.  The step issues ~120 small launches; captured, the host pays one graph launch per
+    segment instead (MI355X_MICROARCH.md, row graph-replay-floor).  Every kernel reads its RNG step
+    and Adam step counters from device memory, so a replay draws fresh numbers.
+
+    Single GPU: one graph.  Data parallel: the collectives (RCCL all-reduce of BatchNorm sums and
+    of the two flat gradient buffers) stay eager on the same stream and cut the step into graph
+    segments, ``[graph, all-reduce, graph, ...]``.
+    """
+
+    def __init__(self, eng, d_steps=1):
+        self.eng, self.d_steps = eng, int(d_steps)
+        self.items = None
+        self._stream = None
+
+    def _body(self):
+        for _ in range(self.d_steps):
+            self.eng.d_step()
+        self.eng.g_step()
+
+    def capture(self):
+        eng = self.eng
+        items = []
+        self._stream = torch.cuda.Stream(device=eng.dev)
+        self._stream.wait_stream(torch.cuda.current_stream(eng.dev))
+        batches = eng.bn_batches
+        with torch.cuda.stream(self._stream):
+            state = {'g': torch.cuda.CUDAGraph()}
+            state['g'].capture_begin()
+
+            def cut(t):
+                state['g'].capture_end()
+                items.append(('graph', state['g']))
+                items.append(('allreduce', t))
+                state['g'] = torch.cuda.CUDAGraph()
+                state['g'].capture_begin()
+
+            eng._ar_hook = cut
+            try:
+                self._body()
+            finally:
+                eng._ar_hook = None
+            state['g'].capture_end()
+            items.append(('graph', state['g']))
+        torch.cuda.current_stream(eng.dev).wait_stream(self._stream)
+        eng.bn_batches = batches              # nothing ran during capture
+        self.items = items
+
+    def run(self):
+        """Execute one step.  The first call runs eagerly (loads the code objects, sets up the
+        communicators) and the second captures; from then on every call is a replay."""
+        eng = self.eng
+        if self.items is None:
+            if self._stream is None:
+                self._stream = False
+                self._body()
+                return
+            self.capture()
+        for kind, obj in self.items:
+            if kind == 'graph':
+                obj.replay()
+            else:
+                eng.dist.allreduce(obj)
+        eng.bn_batches += self.d_steps + 1

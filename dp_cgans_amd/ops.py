@@ -77,11 +77,12 @@ def _mat_strides(t, trans):
 
 
 def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
-         aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=0):
+         aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=0, kscale=None):
     """C = epi(alpha * op(A) @ op(B) + bias) + beta * C on the matrix cores (fp32 MFMA)."""
     for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (aux_out, 'aux_out'), (aux_in, 'aux_in')):
         _chk(t, torch.float32, n)
     _chk(keep, torch.uint8, 'keep')
+    _chk(kscale, torch.float32, 'kscale')
     a_rs, a_cs = _mat_strides(A, trans_a)
     b_rs, b_cs = _mat_strides(B, trans_b)
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
@@ -95,7 +96,7 @@ def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, 
     lib().call('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
                epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
                _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
-               site, leak, splitk, _stream())
+               site, leak, splitk, _p(kscale), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b)))
@@ -248,3 +249,25 @@ def adam_step(p, g, m, v, lr, wd, b1=0.5, b2=0.9, eps=1e-8, clamp=0.0, gscale=1.
 def noise_add_clamp(x, scale, noise_inj=None, rng=None, site=SITE_NOISE_D, clamp=0.0):
     lib().call('dpc_noise_add_clamp', _p(x), x.numel(), scale, _p(noise_inj), _p(rng), site, clamp, _stream())
     return x
+
+
+def persample_gram(delta, act, n, norm2, with_bias=True, accumulate=False):
+    """norm2[i] (+)= squared gradient norm of example i (rows i, n+i, 2n+i) for one Linear layer."""
+    _chk(norm2, torch.float64, 'norm2')
+    if delta.shape[0] != 3 * n or act.shape[0] != 3 * n or norm2.shape[0] != n:
+        raise ValueError('persample_gram: delta/act need 3n rows, norm2 n entries')
+    lib().call('dpc_persample_gram', _p(delta), _ld(delta), delta.shape[1], _p(act), _ld(act), act.shape[1], n,
+               int(with_bias), int(accumulate), _p(norm2), _stream())
+
+
+def clip_factors(norm2, clip, gscale, rowc, roww=None, rowc_w=None, norm_out=None):
+    n = norm2.shape[0]
+    if rowc.shape[0] != 3 * n:
+        raise ValueError('clip_factors: rowc needs 3n entries')
+    lib().call('dpc_clip_factors', _p(norm2), n, float(clip), float(gscale), _p(rowc), _p(roww), _p(rowc_w),
+               _p(norm_out), _stream())
+
+
+def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK):
+    lib().call('dpc_hook_noise', _p(seg_add), seg_add.shape[0], _p(fires), _p(t_dev), float(inv_B), _p(rng), site,
+               _stream())

@@ -51,12 +51,14 @@ int dpc_fill(void* out, int kind, int64_t ld, int64_t rows, int64_t cols, const 
  * one stride of each must be 1.  epi: 0 none; 1 bias+LeakyReLU(leak)+Dropout(0.5): writes
  * slope = (pre>0 ? 1 : leak)*keep*2 to aux_out and C = pre*slope (keep from `keep` u8 [M,N] or
  * Philox idx m*N+n); 2 multiply by aux_in[m,n]; 3 ReLU.  splitk 0 = automatic (fp32 atomics,
- * only for epi 0 and beta in {0,1}). */
+ * only for epi 0 and beta in {0,1}).  kscale (nullable, needs an m-contiguous A, i.e. the
+ * weight-gradient product dW = dY^T X): A(m,k) is multiplied by kscale[k] while it is staged, which
+ * fuses the DP-SGD clip factor of row k into the gradient sum (clip-scale-sum). */
 int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
                  const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
                  const float* bias, int epi, float* aux_out, int64_t ld_aux_out, const float* aux_in,
                  int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep, const uint64_t* rng,
-                 uint32_t site, float leak, int splitk, void* stream);
+                 uint32_t site, float leak, int splitk, const float* kscale, void* stream);
 
 /* tuning / test hook: force the GEMM block tile (64, 128; 0 = automatic).  Host-side state. */
 int dpc_gemm_config(int force_tile);
@@ -170,6 +172,22 @@ int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 /* x = clamp(x + scale * noise): the stand-alone DP noise-add (+ weight clamp) kernel */
 int dpc_noise_add_clamp(float* x, int64_t n, float scale, const float* noise_inj, const uint64_t* rng,
                         uint32_t site, float clamp, void* stream);
+
+/* ---- DP-SGD mode (north_star; the reference has no per-example clipping: SURVEY F2) ------------- */
+/* An example is one pac group i = rows i, n+i, 2n+i (fake, real, penalty) of the stacked
+ * discriminator batch.  norm2[i] (+)= ||gradient of example i w.r.t. one Linear layer||_F^2 computed
+ * from the layer's backward deltas [3n, d] and input activations [3n, K] through two 3x3 Gram
+ * matrices (no per-example gradient is formed); with_bias adds ||delta_i + delta_{n+i}||^2. */
+int dpc_persample_gram(const float* delta, int64_t ldd, int d, const float* act, int64_t lda, int K,
+                       int64_t n, int with_bias, int accumulate, double* norm2, void* stream);
+/* c_i = min(1, clip / (gscale*sqrt(norm2[i]))) -> rowc[p*n+i] (p = 0..2), rowc_w = rowc * roww
+ * (nullable), norm_out[i] = gscale*sqrt(norm2[i]) (nullable). */
+int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,
+                     const float* roww, float* rowc_w, float* norm_out, void* stream);
+/* Reference private mode (dp_cgan.py:638-647): seg_add[s] = N(0,1)_s * sqrt(fires[s]*(t+1)) * inv_B,
+ * the sum of the scalar noises that (t+1) accumulated hook sets add to parameter tensor s. */
+int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
+                   const uint64_t* rng, uint32_t site, void* stream);
 
 #ifdef __cplusplus
 }

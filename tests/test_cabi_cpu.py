@@ -25,7 +25,7 @@ def test_argument_validation_needs_no_gpu():
     from dp_cgans_amd import _lib
     L = _lib.lib()
     rc = L.cdll.dpc_gemm_f32(4, 4, 4, 1.0, None, 4, 1, None, 4, 1, 0.0, None, 4, None, 0, None, 0, None, 0, None, 0,
-                             None, 0, 0.2, 0, None)
+                             None, 0, 0.2, 0, None, None)
     assert rc == -1
     assert b'null operand' in L.cdll.dpc_last_error()
     with pytest.raises(RuntimeError):

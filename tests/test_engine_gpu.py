@@ -195,3 +195,107 @@ def test_engine_sampler_path_matches_oracle_on_same_draws():
     for k in eng.gen.keys:
         sc = float(out['grads'][k.replace('fc.bias', 'fc.weight')].abs().max()) if 'fc.bias' in k else None
         close(eng.gen.G(k), out['grads'][k], rtol=2e-5, scale=sc, what='G grad ' + k)
+
+
+def _flat_noise(eng, seed=11):
+    """N(0,1) noise per discriminator parameter: ({key: cpu tensor}, flat device tensor in the engine's layout)."""
+    g = torch.Generator().manual_seed(seed)
+    per = {k: torch.randn(eng.disc.shapes[k], generator=g) for k in eng.disc.keys}
+    flat = torch.zeros(eng.disc.n)
+    for k in eng.disc.keys:
+        o = eng.disc.offsets[k]
+        flat[o:o + per[k].numel()] = per[k].reshape(-1)
+    return per, flat.to(eng.dev)
+
+
+@pytest.mark.parametrize('clip_quantile', [None, 0.5, 0.0])
+def test_dpsgd_discriminator_update_matches_per_example_oracle(clip_quantile):
+    """DP-SGD mode: per-example (pac group) norms from the Gram kernel, clip factors, fused
+    clip-scale-sum gradient, injected Gaussian noise and Adam, against oracle/dpsgd.py's per-example
+    autograd loop on the inputs of the reference trace.  Clip bounds: above every norm (None),
+    at the median norm, below every norm."""
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import dpsgd
+    from oracle import nets as onets
+    tr = Trace('trace_np.npz')
+    s = tr.kinds.index('D')
+    dev = torch.device('cuda:0')
+    dp = {k: torch.from_numpy(v) for k, v in tr.params(s, 'p_before').items()}
+    gp = {k: torch.from_numpy(v) for k, v in tr.params(tr.kinds.index('G'), 'p_before').items()}
+    inj = injected(tr, s, dev)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [m.cpu() for m in v]) for k, v in inj.items()}
+    n = tr.B // tr.pac
+    mk = lambda g: [m[g * n:(g + 1) * n] for m in cpu['keep']]
+    base = dpsgd.d_step_grads_dpsgd(gp, dp, tr.span_info, tr.pac, cpu['z'], cpu['cond'], cpu['perm'], cpu['real'],
+                                    cpu['exp'], mk(0), mk(1), mk(2), cpu['alpha'], clip=1e30)
+    norms = base['norms'].numpy()
+    clip = {None: float(norms.max()) * 2, 0.5: float(np.median(norms)), 0.0: float(norms.min()) * 0.5}[clip_quantile]
+    sigma = 0.8
+    out = dpsgd.d_step_grads_dpsgd(gp, dp, tr.span_info, tr.pac, cpu['z'], cpu['cond'], cpu['perm'], cpu['real'],
+                                   cpu['exp'], mk(0), mk(1), mk(2), cpu['alpha'], clip=clip)
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, tr.B, tr.pac, dev, private=True, dp_mode='dpsgd',
+                     dp_sigma=sigma, dp_clip=clip)
+    eng.disc.load(dp)
+    eng.gen.load(gp)
+    per, flat = _flat_noise(eng)
+    inj['dp_noise'] = flat
+    eng.d_step(inj)
+    close(eng.norms, out['norms'], what='per-example gradient norms')
+    close(eng.rowc[0:n], out['factors'], what='clip factors')
+    assert torch.equal(eng.rowc[0:n], eng.rowc[n:2 * n]) and torch.equal(eng.rowc[0:n], eng.rowc[2 * n:])
+    for k in tr.dkeys:
+        close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='clipped mean grad ' + k)
+    noisy = dpsgd.add_noise(out['grads'], per, sigma, clip, n)
+    dp2 = onets.apply_update(dp, noisy, {'t': 0, 'm': {}, 'v': {}})
+    for k in tr.dkeys:
+        close(eng.disc.P(k), dp2[k], what='noised + Adam param ' + k)      # no weight clamp in this mode
+
+
+def test_reference_mode_hook_noise_on_device_has_the_reference_variance():
+    """dp_mode='reference' without injection: seg_add[s] = z_s*sqrt(fires_s*(t+1))/B read back through dpc_fill's map."""
+    from dp_cgans_amd import ops
+    from dp_cgans_amd.engine import StepEngine
+    tr = Trace('trace_priv.npz')
+    dev = torch.device('cuda:0')
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, tr.B, tr.pac, dev, private=True)
+    nseg = len(eng.disc.keys)
+    for t in range(3):
+        zs = torch.empty(nseg, device=dev)
+        ops.fill(zs, ops.FILL_NORMAL, eng.rng_shared, ops.SITE_HOOK)
+        eng.disc.t.fill_(t)
+        ops.hook_noise(eng.hook_add, eng.hook_fires, eng.disc.t, 1.0 / eng.gB, eng.rng_shared)
+        want = zs.cpu().numpy() * np.sqrt(eng.hook_fires.cpu().numpy() * (t + 1)) / eng.gB
+        close(eng.hook_add, want, what='hook noise at t=%d' % t)
+        ops.state_advance(eng.rng_shared)
+
+
+@pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
+def test_graph_replay_equals_eager_steps(mode):
+    """The captured step (HIP graph replay) must produce bit-identical parameters to the same
+    number of eager steps from the same seeds."""
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+
+    def make():
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 120, 10, dev, private=True, dp_mode=mode, seed=3)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=9)
+        return eng
+    a, b = make(), make()
+    steps = 5
+    for _ in range(steps):
+        a.d_step()
+        a.d_step()
+        a.g_step()
+    gs = GraphStep(b, d_steps=2)
+    for _ in range(steps):
+        gs.run()
+    torch.cuda.synchronize()
+    assert len(gs.items) == 1
+    assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)
+    assert torch.equal(a.losses, b.losses)
+    assert a.bn_batches == b.bn_batches == steps * 3
+    assert torch.isfinite(a.disc.p).all() and torch.isfinite(a.gen.p).all()

@@ -442,3 +442,57 @@ def test_batchnorm_relu_forward_backward(ops):
     dz = torch.empty(B, F, device=d)
     ops.bn_relu_bwd(dy.to(d), y, zd, mean, invstd, gamma.to(d), dbeta, dgamma, B, dz)
     close(dz, gz, what='dz')
+
+
+# ------------------------------------------------------------------------------------------------
+# DP-SGD kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,d,K', [(7, 5, 13), (50, 32, 940), (64, 1, 24), (33, 256, 4888)])
+def test_persample_gram_and_clip_factors(ops, n, d, K):
+    g = torch.Generator().manual_seed(n + d + K)
+    delta = torch.randn(3 * n, d, generator=g) * 0.1
+    act = torch.randn(3 * n, K, generator=g)
+    ref = torch.zeros(n, dtype=torch.float64)
+    for i in range(n):
+        G = sum(torch.outer(delta[p * n + i].double(), act[p * n + i].double()) for p in range(3))
+        ref[i] = (G ** 2).sum() + ((delta[i] + delta[n + i]).double() ** 2).sum()
+    norm2 = torch.full((n,), 3.0, dtype=torch.float64, device=dev())
+    ops.persample_gram(delta.to(dev()), act.to(dev()), n, norm2, with_bias=True, accumulate=False)
+    close(norm2, ref, what='gram')
+    ops.persample_gram(delta.to(dev()), act.to(dev()), n, norm2, with_bias=False, accumulate=True)
+    ref2 = ref * 2 - torch.stack([((delta[i] + delta[n + i]).double() ** 2).sum() for i in range(n)])
+    close(norm2, ref2, what='gram accumulate')
+    # unaligned views (odd leading dimension / offset): the scalar path
+    big = torch.randn(3 * n, K + 3, generator=g).to(dev())
+    av = big[:, 1:K + 1]
+    ops.persample_gram(delta.to(dev()), av, n, norm2, with_bias=False, accumulate=False)
+    a2 = av.cpu()
+    ref3 = torch.stack([(sum(torch.outer(delta[p * n + i].double(), a2[p * n + i].double()) for p in range(3)) ** 2).sum()
+                        for i in range(n)])
+    close(norm2, ref3, what='gram unaligned')
+    gscale, clip = 4.0, float(torch.sqrt(ref3).median() * 4.0)
+    rowc = torch.empty(3 * n, device=dev())
+    roww = torch.randn(3 * n, generator=g).to(dev())
+    rowcw = torch.empty(3 * n, device=dev())
+    nrm = torch.empty(n, device=dev())
+    ops.clip_factors(norm2, clip, gscale, rowc, roww=roww, rowc_w=rowcw, norm_out=nrm)
+    want_n = gscale * torch.sqrt(ref3)
+    want_c = torch.clamp(clip / want_n, max=1.0).float()
+    close(nrm, want_n, what='norms')
+    close(rowc, want_c.repeat(3), what='clip factors')
+    close(rowcw, want_c.repeat(3) * roww.cpu(), what='weighted clip factors')
+    assert (want_c < 1).any() and (want_c == 1).any()
+
+
+def test_gemm_kscale_is_the_clip_scale_sum(ops):
+    g = torch.Generator().manual_seed(21)
+    for rows, d, K in [(150, 32, 940), (3072, 256, 611), (96, 24, 48)]:
+        dl = torch.randn(rows, d, generator=g)
+        x = torch.randn(rows, K, generator=g)
+        c = torch.rand(rows, generator=g)
+        ref = (dl.double() * c.double()[:, None]).t() @ x.double()
+        out = torch.full((d, K), float('nan'), device=dev())
+        ops.gemm(dl.to(dev()), x.to(dev()), out, trans_a=True, kscale=c.to(dev()))
+        close(out, ref, what='kscale gemm %d' % rows)
+    with pytest.raises(RuntimeError):
+        ops.gemm(dl.to(dev()), dl.to(dev()), torch.empty(96, 96, device=dev()), trans_b=True, kscale=c.to(dev()))

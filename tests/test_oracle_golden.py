@@ -218,3 +218,33 @@ def test_encode_matches_reference():
         _, comp2, _ = oenc.transform_continuous(table[:, ci], g('means'), g('covariances'),
                                                 g('valid'), proba, us[j])
         assert np.array_equal(comp2, comp)
+
+
+def _d_inputs(tr, s):
+    return dict(z=tt(tr.get(s, 'normal')), cond=tt(tr.get(s, 'cond')), exp=tt(tr.exp_full(s)),
+                masks=[[tt(m) for m in grp] for grp in tr.masks(s)], perm=tt(tr.get(s, 'shuffle').astype(np.int64)),
+                real=tt(tr.get(s, 'real').astype(np.float32)), alpha=tt(tr.get(s, 'rand').reshape(-1)))
+
+
+def test_dpsgd_oracle_with_infinite_clip_is_the_reference_gradient():
+    """Anchor of oracle/dpsgd.py: per-example gradients, unclipped and averaged, must be the
+    gradient the reference back-propagates (pen.backward + loss_d.backward, dp_cgan.py:652-655)."""
+    from oracle import dpsgd
+    tr = Trace('trace_np.npz')
+    s = tr.kinds.index('D')
+    dp = {k: tt(v) for k, v in tr.params(s, 'p_before').items()}
+    gp = {k: tt(v) for k, v in tr.params(tr.kinds.index('G'), 'p_before').items()}
+    i = _d_inputs(tr, s)
+    out = dpsgd.d_step_grads_dpsgd(gp, dp, tr.span_info, tr.pac, i['z'], i['cond'], i['perm'], i['real'], i['exp'],
+                                   i['masks'][0], i['masks'][1], i['masks'][2], i['alpha'], clip=1e30)
+    ref_g = tr.params(s, 'g')
+    for k in tr.dkeys:
+        close(out['grads'][k], ref_g[k], rtol=2e-5, what='unclipped per-example mean ' + k)
+    assert float(out['factors'].min()) == 1.0
+    # a finite bound below the smallest norm scales every example to exactly that bound
+    c = float(out['norms'].min()) * 0.5
+    out2 = dpsgd.d_step_grads_dpsgd(gp, dp, tr.span_info, tr.pac, i['z'], i['cond'], i['perm'], i['real'], i['exp'],
+                                    i['masks'][0], i['masks'][1], i['masks'][2], i['alpha'], clip=c)
+    close(out2['factors'] * out2['norms'], np.full(len(out2['norms']), c), what='clipped norms')
+    tot = np.sqrt(sum(float((g.double() ** 2).sum()) for g in out2['grads'].values()))
+    assert tot <= c * (1 + 1e-6)          # mean of vectors of norm c
