@@ -34,6 +34,10 @@ def main():
     ap.add_argument('--pac', type=int, default=8)
     ap.add_argument('--dims', default='256,256')
     ap.add_argument('--d-steps', type=int, default=1)
+    ap.add_argument('--dp-mode', default='dpsgd', choices=['dpsgd', 'reference'],
+                    help="private=True semantics: north_star DP-SGD (per-example clip + Gaussian noise) or the "
+                         "reference's grad-hook noise + weight clamp")
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -41,7 +45,7 @@ def main():
     import torch
     from dp_cgans_amd import ops
     from dp_cgans_amd.data_sampler import DataSampler
-    from dp_cgans_amd.engine import StepEngine
+    from dp_cgans_amd.engine import GraphStep, StepEngine
     from dp_cgans_amd.parallel import Dist
     from dp_cgans_amd.synthetic import build_encoded_table
 
@@ -56,17 +60,20 @@ def main():
     t0 = time.time()
     table, span = build_encoded_table(args.table, dev, n_rows=args.rows)
     sampler = DataSampler(table, span, device=dev, seed=17 + dist.rank)
-    eng = StepEngine(span, 128, dims, dims, args.batch, args.pac, dev, private=True, seed=0, dist=dist)
+    eng = StepEngine(span, 128, dims, dims, args.batch, args.pac, dev, private=True, seed=0, dist=dist,
+                     dp_mode=args.dp_mode, dp_sigma=1.0, dp_clip=1.0)
     eng.sampler = sampler
     torch.cuda.synchronize()
     setup_s = time.time() - t0
 
-    def step():
+    def eager_step():
         for _ in range(args.d_steps):
             eng.d_step()
         eng.g_step()
 
-    for _ in range(args.warmup):
+    gstep = GraphStep(eng, args.d_steps)
+    step = eager_step if args.no_graph else gstep.run
+    for _ in range(max(args.warmup, 2)):      # (first call eager, second captures the graph)
         step()
     torch.cuda.synchronize()
     dist.barrier()
@@ -85,10 +92,12 @@ def main():
         'n_gpus': dist.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s synthetic table (%d rows, 20 continuous + 30 categorical cols), per-GPU batch %d, '
-                               'pac %d, G/D dims %s, private=True (reference hook-noise + weight clamp), '
-                               'discriminator_steps %d; BASELINE.json configs[2]'
-                               % (args.table, table.shape[0], args.batch, args.pac, dims, args.d_steps),
+                               'pac %d, G/D dims %s, private=True (%s), discriminator_steps %d; BASELINE.json configs[2]'
+                               % (args.table, table.shape[0], args.batch, args.pac, dims,
+                                  'DP-SGD: per-example clip C=1 + Gaussian noise sigma=1' if args.dp_mode == 'dpsgd'
+                                  else 'reference hook-noise + weight clamp', args.d_steps),
                    'global_batch': args.batch * dist.world, 'parallelism': 'dp%d' % dist.world,
+                   'launch': 'eager' if args.no_graph else 'hipGraph replay (%d segment(s))' % len(gstep.items or []),
                    'data_dim': eng.Dd, 'cond_dim': eng.C, 'n_discrete': eng.nd, 'setup_s': round(setup_s, 2),
                    'final_losses': [round(x, 5) for x in losses]},
     }
@@ -100,7 +109,7 @@ def main():
         nprof = min(args.steps, 20)
         if dist.world == 1:
             for _ in range(nprof):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             prof = ops.GEMM_PROFILE
             ops.GEMM_PROFILE = None
@@ -127,6 +136,24 @@ def main():
         out['dp_noise_clamp'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': gbs / HBM_PEAK_GBS, 'elements': n_el}
         del x
+        # DP clip kernel (per-example Gram / ghost norm, HBM-bound): 3n rows of K0 + d floats read once
+        K0, dd = eng.K0, eng.ddim[0]
+        nn = 16384
+        act = torch.randn(3 * nn, K0, device=dev)
+        dl = torch.randn(3 * nn, dd, device=dev)
+        n2 = torch.zeros(nn, dtype=torch.float64, device=dev)
+        for _ in range(2):
+            ops.persample_gram(dl, act, nn, n2)
+        e0.record()
+        for _ in range(5):
+            ops.persample_gram(dl, act, nn, n2)
+        e1.record()
+        torch.cuda.synchronize()
+        gbs = 4.0 * 3 * nn * (K0 + dd) * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        out['dp_clip_norm'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': gbs / HBM_PEAK_GBS, 'examples': nn, 'row_floats': K0 + dd,
+                               'kernel': 'persample_gram_kernel'}
+        del act, dl, n2
 
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(eng, span, args)
@@ -169,8 +196,9 @@ def cpu_baseline(eng, span, args):
         t_total += time.perf_counter() - t0
         steps += 1
     return {'value': B * steps / t_total, 'unit': 'rows/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d full D+G steps at batch %d (torch-CPU autograd restatement, closed-form cond loss, '
-                      'host sampling excluded), %.1f s' % (steps, B, t_total)}
+            'sample': '%d full D+G steps at batch %d (torch-CPU autograd restatement of the reference step: '
+                      "its private=True is hook noise + weight clamp, not per-example clipping; closed-form cond "
+                      'loss, host sampling excluded), %.1f s' % (steps, B, t_total)}
 
 
 if __name__ == '__main__':

@@ -233,6 +233,30 @@ extern "C" int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t*
   return DPC_OK;
 }
 
+// Tables without discrete columns: row_id[b] = floor(u_b * N), u from u_inj or Philox
+// (np.random.randint(len(data), size=n), data_sampler.py:388-390, in distribution).
+__global__ __launch_bounds__(256) void row_uniform_kernel(int64_t N, const double* __restrict__ u_inj,
+                                                          const uint64_t* rng, uint32_t site, int64_t B,
+                                                          int64_t* __restrict__ row_id) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double u = u_inj ? u_inj[b]
+                   : dpc_u64_to_unit(dpc_draw_u32(rng, site, 2 * (uint64_t)b), dpc_draw_u32(rng, site, 2 * (uint64_t)b + 1));
+  int64_t r = (int64_t)(u * (double)N);
+  row_id[b] = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+}
+
+extern "C" int dpc_row_uniform(int64_t N, const double* u_inj, const uint64_t* rng, uint32_t site, int64_t B,
+                               int64_t* row_id, void* stream) {
+  DPC_CHECK_ARG(row_id && N > 0 && B >= 0, "row_uniform: bad argument");
+  DPC_CHECK_ARG(u_inj || rng, "row_uniform: no random source");
+  if (B == 0) return DPC_OK;
+  hipLaunchKernelGGL(row_uniform_kernel, dim3((unsigned)dpc_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, N, u_inj,
+                     rng, site, B, row_id);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
 // out[b, 0:Dd] = table[row_id[b], 0:Dd]; optionally out[b, Dd + c] = 1 at the two categories of
 // request src = perm ? perm[b] : b (the cond vector that travels with the real row, c1[perm]).
 __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict__ table, int64_t ld,

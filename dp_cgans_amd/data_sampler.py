@@ -15,14 +15,19 @@ class DataSampler(object):
     flattened int array [n_spans, 3] = (dim, is_softmax, spans_in_column).
     """
 
-    def __init__(self, data, output_info, log_frequency=True, device='cuda:0', seed=0):
+    def __init__(self, data, output_info, log_frequency=True, device='cuda:0', seed=0, reference_quirks=True):
         self.dev = torch.device(device)
+        # The reference never fills _discrete_column_matrix_st (data_sampler.py:19-20, SURVEY Q9), so
+        # sample_original_condvec / generate_cond_from_condition_column_info read column 0's span for
+        # every discrete column.  reference_quirks=True keeps that; False uses the real offsets.
+        self.reference_quirks = reference_quirks
         span_info = flatten_output_info(output_info)
         self.span_info = span_info
         _, cols, _, _ = span_tables(span_info)
         self._n_discrete_columns = len(cols)
         self._n_categories = int(sum(c[2] for c in cols))
         self._categories_each_column = np.array([c[2] for c in cols], dtype=np.int64)
+        self._matrix_st = np.array([c[0] for c in cols], dtype=np.int64)
         self._log_frequency = log_frequency     # kept for interface parity; the pair path never reads it (SURVEY F5)
         if torch.is_tensor(data):
             self.table = data.to(self.dev, torch.float32).contiguous()
@@ -129,9 +134,21 @@ class DataSampler(object):
         cst = self.cond_st.cpu().numpy()
         for i in range(batch):
             c = int(cols[i])
-            pick = int(np.argmax(tab[i, 0:dims[c]]))
+            st = 0 if self.reference_quirks else int(self._matrix_st[c])
+            pick = int(np.argmax(tab[i, st:st + dims[c]]))
             cond[i, pick + cst[c]] = 1
         return cond
+
+    def generate_cond_from_condition_column_info(self, condition_info, batch):
+        """data_sampler.py:401-406 (the reference adds value_id to a matrix offset that is always 0, Q9)."""
+        vec = np.zeros((batch, self._n_categories), dtype='float32')
+        c = condition_info['discrete_column_id']
+        if self.reference_quirks:
+            idx = condition_info['value_id']
+        else:
+            idx = int(self.cond_st[c].item()) + condition_info['value_id']
+        vec[:, idx] = 1
+        return vec
 
 
 def flatten_output_info(output_info):

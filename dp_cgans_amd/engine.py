@@ -107,6 +107,7 @@ class StepEngine(object):
                  weight_clip=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
+        self.span_info_np = np.asarray(span_info, dtype=np.int32).reshape(-1, 3)
         spans, cols, col2d, col2c = span_tables(span_info)
         self.Dd = int(spans[:, 1].sum())
         self.nd = len(cols)
@@ -250,6 +251,16 @@ class StepEngine(object):
     def discriminator_state_dict(self):
         return self.disc.state_dict()
 
+    def load_generator_state_dict(self, sd):
+        """Accepts the reference Generator's state_dict (keys/shapes of SURVEY 3.5)."""
+        self.gen.load(sd)
+        for k in self.bn_run:
+            if k in sd:
+                self.bn_run[k].copy_(torch.as_tensor(sd[k]).to(self.dev, torch.float32))
+        k = 'seq.0.bn.num_batches_tracked'
+        if k in sd:
+            self.bn_batches = int(sd[k])
+
     # ------------------------------------------------------------------------------------------
     # pieces
     # ------------------------------------------------------------------------------------------
@@ -266,8 +277,13 @@ class StepEngine(object):
         else:
             ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
         if not self.has_cond:
-            if need_real:
-                raise NotImplementedError('tables without discrete columns are not supported by the device sampler yet')
+            if need_real:     # uniform rows (data_sampler.py:388-390)
+                real = self.Xd[B:2 * B]
+                if 'real' in inj:
+                    real.copy_(inj['real'])
+                else:
+                    ops.row_uniform(self.sampler.N, self.row_id, u_inj=inj.get('u_row'), rng=self.rng)
+                    ops.row_gather(self.sampler.table, self.row_id, real, Dd)
             return
         fake_c = self.Xd[0:B, Dd:]
         if 'cond' in inj:
@@ -322,16 +338,26 @@ class StepEngine(object):
             ops.apply_activate_fwd(self.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng)
             dst.copy_(self.fake)
 
-    def _disc_forward(self, rows, inj):
+    def _disc_forward(self, rows, inj, row0=0):
         d = self.disc
-        x = self.Xd3[0:rows]
+        rs = slice(row0, row0 + rows)
+        x = self.Xd3[rs]
         keeps = inj.get('keep')
         for i in range(self.M):
-            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][0:rows], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
-                     epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][0:rows], keep=keeps[i] if keeps else None,
+            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
+                     epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
                      rng=self.rng, site=ops.SITE_DROP0 + i, leak=LEAK)
-            x = self.H[i][0:rows]
-        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * self.M)), d.P('seq.%d.bias' % (3 * self.M)), self.y[0:rows])
+            x = self.H[i][rs]
+        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * self.M)), d.P('seq.%d.bias' % (3 * self.M)), self.y[rs])
+
+    def score_real_rows(self, inj=None):
+        """Discriminator output on a freshly sampled batch of real rows with their cond vectors
+        (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
+        inj = inj or {}
+        self._draw_inputs(inj, need_real=True)
+        self._disc_forward(self.n, inj, row0=self.n)
+        ops.state_advance(self.rng)
+        return self.y[self.n:2 * self.n].detach().cpu().view(-1, 1)
 
     def _disc_chain_down(self, rows, rowscale):
         """D_M = rowscale * w_last * S_M;  D_{i-1} = (D_i W_i) * S_{i-1}."""

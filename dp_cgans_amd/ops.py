@@ -161,6 +161,12 @@ def row_select(bitmaps, sel, gcount, row_id, perm=None, k_inj=None, rng=None, si
     return row_id
 
 
+def row_uniform(N, row_id, u_inj=None, rng=None, site=SITE_ROWPICK):
+    _chk(u_inj, torch.float64, 'u_inj')
+    lib().call('dpc_row_uniform', N, _p(u_inj), _p(rng), site, row_id.shape[0], _p(row_id), _stream())
+    return row_id
+
+
 def row_gather(table, row_id, out, Dd, sel=None, perm=None, C=0):
     lib().call('dpc_row_gather', _p(table), _ld(table), _p(row_id), row_id.shape[0], Dd, _p(out), _ld(out), _p(sel),
                _p(perm), C, _stream())

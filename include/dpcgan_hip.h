@@ -104,6 +104,9 @@ int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const in
 int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,
                    const int64_t* perm, const int64_t* k_inj, const uint64_t* rng, uint32_t site,
                    int64_t B, int64_t* row_id, void* stream);
+/* tables without discrete columns (data_sampler.py:388-390): row_id[b] = floor(u_b * N) */
+int dpc_row_uniform(int64_t N, const double* u_inj, const uint64_t* rng, uint32_t site, int64_t B,
+                    int64_t* row_id, void* stream);
 /* self._data[idx] (data_sampler.py:396) + the cond vector that travels with it (c_pair_1[perm],
  * dp_cgan.py:607) written behind the row when sel != NULL. */
 int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd,
