@@ -151,17 +151,18 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
 extern "C" int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
                              int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
                              float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
-                             int n_partials, void* stream) {
+                             int n_partials, int64_t B_total, void* stream) {
   DPC_CHECK_ARG(fake && cond && mask && col2d && col2c && loss_out && partials, "cond_loss: null pointer");
   DPC_CHECK_ARG(B > 0 && Dd > 0 && nd > 0, "cond_loss: bad shape");
   DPC_CHECK_ARG(n_partials >= 1, "cond_loss: workspace too small");
   int grid = dpc_grid(B * Dd, 256);
   if (grid > n_partials) grid = n_partials;
-  float scale = (float)(2.0 / ((double)B * (double)nd));
+  if (B_total <= 0) B_total = B;      // data parallel: B rows of a global batch of B_total
+  float scale = (float)(2.0 / ((double)B_total * (double)nd));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cond_loss_kernel, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d, col2c, B,
                      Dd, scale, dfake, lddf, accumulate, partials);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B * (double)nd), loss_out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B_total * (double)nd), loss_out);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -240,6 +240,13 @@ class StepEngine(object):
             self.disc.P('seq.%d.weight' % (3 * i)).copy_(w)
             self.disc.P('seq.%d.bias' % (3 * i)).copy_(b)
 
+    def global_losses(self):
+        """[loss_d, penalty, -mean(y_fake), cond loss] of the latest updates over the GLOBAL batch
+        (every entry of ``losses`` is this rank's additive share)."""
+        t = self.losses.clone()
+        self.dist.allreduce(t)
+        return t.cpu().numpy()
+
     def generator_state_dict(self):
         sd = self.gen.state_dict()
         for k, v in self.bn_run.items():
@@ -301,7 +308,7 @@ class StepEngine(object):
         real = self.Xd[B:2 * B]
         if 'real' in inj:
             real[:, :Dd].copy_(inj['real'])
-            real[:, Dd:].copy_(self.cond[inj['perm']])
+            real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else self.cond[inj['perm']])
         else:
             s = self.sampler
             if 'perm' in inj:
@@ -391,7 +398,7 @@ class StepEngine(object):
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
                         rng=self.rng)
         self._disc_forward(3 * n, inj)
-        ops.mean_pair(self.y, n, 1.0, -1.0, self.losses[0:1])
+        ops.mean_pair(self.y, n, n / self.gn, -n / self.gn, self.losses[0:1])      # this rank's share of the global means
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
         self._disc_chain_down(3 * n, self.rowscale_d)
         W1 = d.P('seq.0.weight')
@@ -461,13 +468,13 @@ class StepEngine(object):
         self._gen_forward()
         self._activate(inj)
         self._disc_forward(n, inj)
-        ops.mean_pair(self.y, n, -1.0, 0.0, self.losses[2:3])
+        ops.mean_pair(self.y, n, -n / self.gn, 0.0, self.losses[2:3])
         self._disc_chain_down(n, self.rowscale_g)
         ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
         if self.has_cond:
             ops.apply_activate_bwd(self.Xd[0:B, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
             ops.cond_loss(self.fake, self.cond, self.mask, self.col2d, self.col2c, self.nd, self.losses[3:4],
-                          self.dfake, self.part_loss, accumulate=True)
+                          self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
         else:
             self.dfake.copy_(self.dX)
             self.losses[3:4].zero_()

@@ -116,13 +116,13 @@ def apply_activate_bwd(y, dy, dx, spans, tau=0.2, accumulate=False):
     return dx
 
 
-def cond_loss(fake, cond, mask, col2d, col2c, nd, loss_out, dfake, partials, accumulate=False):
+def cond_loss(fake, cond, mask, col2d, col2c, nd, loss_out, dfake, partials, accumulate=False, batch_total=0):
     _chk(mask, torch.int32, 'mask')
     _chk(partials, torch.float64, 'partials')
     B, Dd = fake.shape
     lib().call('dpc_cond_loss', _p(fake), _ld(fake), _p(cond), _ld(cond), _p(mask), _ld(mask), _p(col2d), _p(col2c), B,
                Dd, nd, _p(loss_out), _p(dfake), _ld(dfake) if dfake is not None else 0, int(accumulate), _p(partials),
-               partials.numel(), _stream())
+               partials.numel(), int(batch_total), _stream())
     return loss_out
 
 

@@ -20,14 +20,22 @@ class Dist(object):
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                backend = os.environ.get('DPCGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(self.local_rank)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+        self.backend = dist.get_backend() if self.active else None
 
     def allreduce(self, t):
+        """In-place sum over ranks.  RCCL reduces device buffers directly; under gloo (CPU rehearsal,
+        or several ranks sharing one GPU in the tests) device tensors are staged through the host."""
         if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if t.is_cuda and self.backend == 'gloo':
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
     def barrier(self):
@@ -35,7 +43,7 @@ class Dist(object):
             dist.barrier()
 
     def max_float(self, x, device):
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device='cpu' if self.backend == 'gloo' else device)
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

@@ -191,7 +191,7 @@ class DPCGANSynthesizer(object):
                     for _ in range(self._discriminator_steps):
                         eng.d_step()
                     eng.g_step()
-            losses = eng.losses.cpu().numpy()        # one sync per epoch, as the reference's .item() (dp_cgan.py:735-736)
+            losses = eng.global_losses()              # one sync per epoch, as the reference's .item() (dp_cgan.py:735-736)
             generator_loss = float(losses[2] + losses[3])
             discriminator_loss = float(losses[0])
             rows.append((i, generator_loss, discriminator_loss))

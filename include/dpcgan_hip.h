@@ -77,11 +77,12 @@ int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t
 /* ---- conditional loss (DPCGANSynthesizer._cond_loss_pair, dp_cgan.py:330-389), closed form --- */
 /* loss_out[0] = 2/(B*nd) sum_b sum_j mask[b,col2d[j]] * BCEWithLogits(fake[b,j], cond[b,col2c[j]]);
  * dfake (nullable) gets d loss / d fake (zero outside discrete columns).  partials: fp64 workspace
- * of n_partials (>= 1, 2048 is enough) elements. */
+ * of n_partials (>= 1, 2048 is enough) elements.  B_total > 0: these B rows are one rank's shard of a
+ * global batch of B_total rows (the 1/B of the mean uses B_total, so shares add up over ranks). */
 int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
                   int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
                   float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
-                  int n_partials, void* stream);
+                  int n_partials, int64_t B_total, void* stream);
 
 /* ---- DataSampler (data_sampler.py) ---------------------------------------------------------- */
 /* Tables (replace DataSampler.__init__, data_sampler.py:9-198): bitmaps[C][W] row sets per

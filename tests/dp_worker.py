@@ -1,0 +1,125 @@
+"""Worker of the data-parallel tests (one process per rank; launched by test_parallel_*.py).
+
+mode 'replay': every rank replays its shard of the reference trace (rows [r*B/R, (r+1)*B/R) of every
+injected tensor) through StepEngine with the collectives of parallel.Dist; rank 0 checks gradients
+and weights against the single-process values recorded from the reference.
+mode 'graph': Philox-driven steps, eager engine vs graph-segment engine on every rank.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def shard(x, r, R, groups=False):
+    n = x.shape[0] // R
+    return x[r * n:(r + 1) * n]
+
+
+def replay(dist, dev):
+    from golden_util import Trace
+    from dp_cgans_amd.engine import StepEngine
+    from test_engine_gpu import AdamAwareCompare, close, injected
+    tr = Trace('trace_np.npz')
+    R, r = dist.world, dist.rank
+    Bl = tr.B // R
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, Bl, tr.pac, dev, private=False, dist=dist,
+                     global_batch=tr.B)
+    eng.disc.load(tr.params(tr.kinds.index('D'), 'p_before'))
+    eng.gen.load(tr.params(tr.kinds.index('G'), 'p_before'))
+    cmp_d, cmp_g = AdamAwareCompare(), AdamAwareCompare()
+    for s, kind in enumerate(tr.kinds):
+        full = injected(tr, s, dev)
+        n = tr.B // tr.pac
+        inj = {k: shard(full[k], r, R) for k in ('z', 'cond', 'mask', 'exp')}
+        # dropout masks are stacked [fake groups | real groups | interpolate groups]: shard each block
+        nblk = 3 if kind == 'D' else 1
+        inj['keep'] = [torch.cat([shard(m[b * n:(b + 1) * n], r, R) for b in range(nblk)]) for m in full['keep']]
+        if kind == 'D':
+            inj['real'] = shard(full['real'], r, R)
+            inj['real_cond'] = shard(full['cond'][full['perm']], r, R)
+            inj['alpha'] = shard(full['alpha'], r, R)
+            eng.d_step(inj)
+            ref_g, ref_p = tr.params(s, 'g'), tr.params(s, 'p_after')
+            cmp_d.steps += 1
+            losses = eng.global_losses()
+            if r == 0:
+                for k in tr.dkeys:
+                    close(eng.disc.G(k), ref_g[k], rtol=2e-5, what='s%d D grad %s' % (s, k))
+                    cmp_d.check(k, eng.disc.P(k), ref_p[k], ref_g[k], 's%d D param %s' % (s, k))
+                close(losses[1:2], [float(tr.get(s, 'pen'))], what='pen')
+                ysc = max(abs(float(tr.get(s, 'd_out', 0).mean())), abs(float(tr.get(s, 'd_out', 1).mean())))
+                close(losses[0:1], [float(tr.get(s, 'backward_value', 1))], scale=ysc, what='loss_d')
+        else:
+            eng.g_step(inj)
+            ref_g, ref_p = tr.params(s, 'g'), tr.params(s, 'p_after')
+            cmp_g.steps += 1
+            losses = eng.global_losses()
+            if r == 0:
+                close(losses[3:4], [float(tr.get(s, 'ce'))], what='ce')
+                close([losses[2] + losses[3]], [float(tr.get(s, 'backward_value', 0))], what='loss_g')
+                for k in tr.gkeys:
+                    sc = np.abs(ref_g[k.replace('fc.bias', 'fc.weight')]).max() if 'fc.bias' in k else None
+                    close(eng.gen.G(k), ref_g[k], rtol=2e-5, scale=sc, what='s%d G grad %s' % (s, k))
+                    if 'fc.bias' not in k:
+                        cmp_g.check(k, eng.gen.P(k), ref_p[k], ref_g[k], 's%d G param %s' % (s, k))
+    # replicas stay identical
+    a = eng.disc.p.clone()
+    dist.allreduce(a)
+    assert torch.allclose(a, eng.disc.p * R, rtol=0, atol=0), 'discriminator replicas diverged'
+    sd = eng.generator_state_dict()
+    if r == 0:
+        for k in tr.z.files:
+            if k.startswith('gen_final/') and 'running' in k:
+                close(sd[k[len('gen_final/'):]], tr.z[k], what=k)
+
+
+def graph(dist, dev, mode):
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+
+    def make():
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=dist)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=9 + dist.rank)
+        return eng
+    a, b = make(), make()
+    for _ in range(4):
+        a.d_step()
+        a.g_step()
+    gs = GraphStep(b, d_steps=1)
+    for _ in range(4):
+        gs.run()
+    torch.cuda.synchronize()
+    assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
+    assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)
+    chk = a.disc.p.clone()
+    dist.allreduce(chk)
+    assert torch.equal(chk, a.disc.p * dist.world), 'replicas diverged'
+    assert torch.isfinite(a.gen.p).all()
+
+
+def main():
+    mode = sys.argv[1]
+    from dp_cgans_amd.parallel import Dist
+    dist = Dist(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    if mode == 'replay':
+        replay(dist, dev)
+    else:
+        graph(dist, dev, sys.argv[2])
+    dist.barrier()
+    dist.shutdown()
+    print('rank %d ok' % dist.rank)
+
+
+if __name__ == '__main__':
+    main()

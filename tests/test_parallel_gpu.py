@@ -1,0 +1,52 @@
+"""Data-parallel step, 2 ranks sharing the one GPU of the test box (collectives over gloo, staged
+through the host; RCCL needs one GPU per rank, which only the driver's 8-GPU run has).  What is
+checked is the product's sharding algebra: BatchNorm from all-reduced column sums, loss means and
+penalty scaled by the GLOBAL batch, flat-gradient all-reduce, identical replicas, and the HIP-graph
+segmentation at the collectives."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args, world=2, timeout=240):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py')] + args, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-4000:])
+
+
+def test_two_ranks_replay_the_reference_trace():
+    launch(['replay'])
+
+
+@pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
+def test_two_ranks_graph_segments_equal_eager(mode):
+    launch(['graph', mode])
