@@ -41,25 +41,39 @@ extern "C" int dpc_build_bitmaps(const float* table, int64_t ld, int64_t N, cons
   return DPC_OK;
 }
 
-// cnt[a][b] for one (a, b) per block.
+// cnt[a][b] (and, when cntblk != NULL, the same count split over S superblocks of Wb = ceil(W/S)
+// bitmap words) for one (a, b) per block.  Wave w of the block takes superblocks w, w+4, ...
 __global__ __launch_bounds__(256) void cooccurrence_kernel(const uint64_t* __restrict__ bitmaps, int64_t W, int C,
-                                                           int32_t* __restrict__ cnt) {
+                                                           int32_t* __restrict__ cnt, int32_t* __restrict__ cntblk,
+                                                           int S, int64_t Wb) {
   __shared__ long long red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int64_t pair = blockIdx.x;
   int a = (int)(pair / C), b = (int)(pair - (int64_t)a * C);
   const uint64_t* pa = bitmaps + (int64_t)a * W;
   const uint64_t* pb = bitmaps + (int64_t)b * W;
   long long acc = 0;
-  for (int64_t w = threadIdx.x; w < W; w += blockDim.x) acc += __popcll(pa[w] & pb[w]);
+  for (int sb = wave; sb < S; sb += 4) {
+    int64_t w0 = (int64_t)sb * Wb, w1 = min(W, w0 + Wb);
+    int c = 0;
+    for (int64_t w = w0 + lane; w < w1; w += 64) c += __popcll(pa[w] & pb[w]);
+    c = dpc_wave_sum(c);
+    if (lane == 0) {
+      if (cntblk) cntblk[pair * S + sb] = c;
+      acc += c;
+    }
+  }
   long long tot = dpc_block_sum(acc, red);
   if (threadIdx.x == 0) cnt[pair] = (int32_t)tot;
 }
 
-extern "C" int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, void* stream) {
+extern "C" int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, int32_t* cntblk, int S,
+                                void* stream) {
   DPC_CHECK_ARG(bitmaps && cnt && W > 0 && C > 0, "cooccurrence: bad argument");
   DPC_CHECK_ARG((int64_t)C * C < 2147483647LL, "cooccurrence: C*C exceeds the grid limit");
+  DPC_CHECK_ARG(S >= 1 && S <= 64 && (cntblk || S == 1), "cooccurrence: 1 <= S <= 64, S > 1 needs cntblk");
   hipLaunchKernelGGL(cooccurrence_kernel, dim3((unsigned)((int64_t)C * C)), dim3(256), 0, (hipStream_t)stream, bitmaps,
-                     W, C, cnt);
+                     W, C, cnt, cntblk, S, dpc_cdiv(W, S));
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -154,21 +168,33 @@ extern "C" int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_s
 
 // ---------------------------------------------------------------------------------------------
 // sample_data_pair: row_id[b] = k-th (0-based) set bit of bitmaps[ca] & bitmaps[cb], where
-// (ca, cb) = sel[src], src = perm ? perm[b] : b.  One block per request; tiles of 1024 words,
-// block-wide popcount scan, early exit once the running count passes k.
+// (ca, cb) = sel[src], src = perm ? perm[b] : b.  One wave per request: the superblock that holds
+// the k-th match comes from a wave-wide scan of the pair's S superblock counts (cntblk), then only
+// that superblock's Wb words of the two bitmaps are scanned, 64 words per step (popcount, wave
+// prefix sum, ballot).  Reads ~2*Wb*8 + 4*S bytes per request instead of half of both bitmaps.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpc_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void row_select_kernel(const uint64_t* __restrict__ bitmaps, int64_t W,
                                                          const int32_t* __restrict__ sel,
                                                          const int64_t* __restrict__ gcount,
                                                          const int64_t* __restrict__ perm,
                                                          const int64_t* __restrict__ k_inj, const uint64_t* rng,
-                                                         uint32_t site, int64_t B, int64_t* __restrict__ row_id) {
-  __shared__ int wsum[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+                                                         uint32_t site, int64_t B, int64_t* __restrict__ row_id,
+                                                         const int32_t* __restrict__ cntblk, int C, int S, int64_t Wb) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
     int64_t src = perm ? perm[b] : b;
-    const uint64_t* pa = bitmaps + (int64_t)sel[2 * src] * W;
-    const uint64_t* pb = bitmaps + (int64_t)sel[2 * src + 1] * W;
+    const int ca = sel[2 * src], cb = sel[2 * src + 1];
+    const uint64_t* pa = bitmaps + (int64_t)ca * W;
+    const uint64_t* pb = bitmaps + (int64_t)cb * W;
     int64_t cntg = gcount[src];
     int64_t k;
     if (k_inj) k = k_inj[b];
@@ -178,57 +204,54 @@ __global__ __launch_bounds__(256) void row_select_kernel(const uint64_t* __restr
       if (k > cntg - 1) k = cntg - 1;
     }
     if (k < 0 || k >= cntg) {           // empty group or bad injected rank: defined result, no scan
-      if (threadIdx.x == 0) row_id[b] = -1;
+      if (lane == 0) row_id[b] = -1;
       continue;
     }
-    int64_t base = 0;
-    for (int64_t t0 = 0; t0 < W; t0 += 1024) {
-      int64_t w0 = t0 + 4 * (int64_t)threadIdx.x;
-      uint64_t x[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = (w0 + q < W) ? (pa[w0 + q] & pb[w0 + q]) : 0ull;
-      int c = __popcll(x[0]) + __popcll(x[1]) + __popcll(x[2]) + __popcll(x[3]);
-      int incl = c;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        int n = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += n;
-      }
-      __syncthreads();
-      if (lane == 63) wsum[wave] = incl;
-      __syncthreads();
-      int woff = 0, ttot = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < wave) woff += wsum[q];
-        ttot += wsum[q];
-      }
-      int64_t excl = base + woff + incl - c;
-      if (k >= excl && k < excl + c) {
-        int kk = (int)(k - excl);
-        int q = 0;
-        while (kk >= __popcll(x[q])) { kk -= __popcll(x[q]); ++q; }
-        uint64_t wv = x[q];
-        for (int i = 0; i < kk; ++i) wv &= wv - 1;
-        row_id[b] = (w0 + q) * 64 + (__ffsll((long long)wv) - 1);
-      }
-      base += ttot;
-      if (base > k) break;
+    int64_t w0 = 0, w1 = W;
+    if (cntblk) {
+      int c = lane < S ? cntblk[((int64_t)ca * C + cb) * S + lane] : 0;
+      int incl = dpc_wave_incl_scan(c, lane);
+      unsigned long long m = __ballot((int64_t)incl > k);      // non-empty: the S counts sum to cntg > k
+      int sb = __ffsll((long long)m) - 1;
+      int excl = __shfl(incl - c, sb, 64);
+      k -= excl;
+      w0 = (int64_t)sb * Wb;
+      w1 = min(W, w0 + Wb);
     }
-    __syncthreads();
+    int64_t found = -1;
+    for (int64_t w = w0; w < w1; w += 64) {
+      uint64_t x = (w + lane < w1) ? (pa[w + lane] & pb[w + lane]) : 0ull;
+      int c = __popcll(x);
+      int incl = dpc_wave_incl_scan(c, lane);
+      unsigned long long m = __ballot((int64_t)incl > k);
+      if (m) {
+        int l = __ffsll((long long)m) - 1;
+        if (lane == l) {
+          int kk = (int)(k - (incl - c));
+          uint64_t wv = x;
+          for (int i = 0; i < kk; ++i) wv &= wv - 1;
+          found = (w + lane) * 64 + (__ffsll((long long)wv) - 1);
+          row_id[b] = found;
+        }
+        break;                           // wave-uniform
+      }
+      k -= __shfl(incl, 63, 64);
+    }
   }
 }
 
 extern "C" int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,
                               const int64_t* perm, const int64_t* k_inj, const uint64_t* rng, uint32_t site, int64_t B,
-                              int64_t* row_id, void* stream) {
+                              int64_t* row_id, const int32_t* cntblk, int C, int S, void* stream) {
   DPC_CHECK_ARG(bitmaps && sel && gcount && row_id, "row_select: null pointer");
   DPC_CHECK_ARG(k_inj || rng, "row_select: no random source");
   DPC_CHECK_ARG(W > 0 && B >= 0, "row_select: bad shape");
+  DPC_CHECK_ARG(!cntblk || (C > 0 && S >= 1 && S <= 64), "row_select: superblock table needs C and 1 <= S <= 64");
   if (B == 0) return DPC_OK;
-  int grid = (int)(B < 8192 ? B : 8192);
+  int64_t blocks = dpc_cdiv(B, 4);
+  int grid = (int)(blocks < 8192 ? blocks : 8192);
   hipLaunchKernelGGL(row_select_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bitmaps, W, sel, gcount, perm,
-                     k_inj, rng, site, B, row_id);
+                     k_inj, rng, site, B, row_id, cntblk, C, S, cntblk ? dpc_cdiv(W, S) : W);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(256) void perm_keys_kernel(const uint64_t* rng, uin
 // 1024 keys sort before them; integer atomics, so the result does not depend on arrival order.
 __global__ __launch_bounds__(256) void perm_count_kernel(const uint64_t* __restrict__ keys, int64_t B,
                                                          unsigned long long* __restrict__ ranks) {
-  __shared__ uint64_t tile[1024];
+  __shared__ __attribute__((aligned(16))) uint64_t tile[1024];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t j0 = (int64_t)blockIdx.y * 1024;
   for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < B) ? keys[j0 + q] : ~0ull;
@@ -311,9 +334,15 @@ __global__ __launch_bounds__(256) void perm_count_kernel(const uint64_t* __restr
   uint64_t ki = keys[i];
   int lim = (int)min((int64_t)1024, B - j0);
   unsigned cnt = 0;
-  for (int j = 0; j < lim; ++j) {
-    uint64_t kj = tile[j];
-    cnt += (kj < ki) || (kj == ki && (j0 + j) < i);
+  // keys past the end are ~0 (never below a real key; equal only to a real ~0 key, where the index
+  // tie-break keeps them out), so the loop runs over the whole tile with 16-byte LDS reads
+  (void)lim;
+  const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile);
+#pragma unroll 8
+  for (int j = 0; j < 512; ++j) {
+    ulonglong2 kk = t2[j];
+    cnt += (kk.x < ki) || (kk.x == ki && (j0 + 2 * j) < i);
+    cnt += (kk.y < ki) || (kk.y == ki && (j0 + 2 * j + 1) < i);
   }
   if (cnt) atomicAdd(&ranks[i], (unsigned long long)cnt);
 }

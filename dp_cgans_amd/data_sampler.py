@@ -15,7 +15,8 @@ class DataSampler(object):
     flattened int array [n_spans, 3] = (dim, is_softmax, spans_in_column).
     """
 
-    def __init__(self, data, output_info, log_frequency=True, device='cuda:0', seed=0, reference_quirks=True):
+    def __init__(self, data, output_info, log_frequency=True, device='cuda:0', seed=0, reference_quirks=True,
+                 superblock_bytes=4 << 30):
         self.dev = torch.device(device)
         # The reference never fills _discrete_column_matrix_st (data_sampler.py:19-20, SURVEY Q9), so
         # sample_original_condvec / generate_cond_from_condition_column_info read column 0's span for
@@ -47,8 +48,12 @@ class DataSampler(object):
         self.W = (self.N + 63) // 64
         self.bitmaps = torch.zeros(C, self.W, dtype=torch.int64, device=self.dev)
         self.cnt = torch.zeros(C, C, dtype=torch.int32, device=self.dev)
+        # superblock split of the counts for the row pick: S <= 64 superblocks, at least 16 bitmap words
+        # each, at most ~4 GiB of table (288 GB of HBM: 20 MB at T1M, 3 superblocks at C = 18 000)
+        S = int(max(1, min(64, self.W // 16, superblock_bytes // (4 * C * C))))
+        self.cntblk = torch.zeros(C, C, S, dtype=torch.int32, device=self.dev) if S > 1 else None
         ops.build_bitmaps(self.table, self.cat_col, self.bitmaps)
-        ops.cooccurrence(self.bitmaps, self.cnt)
+        ops.cooccurrence(self.bitmaps, self.cnt, self.cntblk)
         self._last_sel = None
 
     def dim_cond_vec(self):
@@ -97,7 +102,7 @@ class DataSampler(object):
         src = torch.from_numpy(first[pos].astype(np.int64)).to(d)
         kd = torch.as_tensor(np.asarray(k, dtype=np.int64)).to(d) if k is not None else None
         rid = torch.empty(n, dtype=torch.int64, device=d)
-        ops.row_select(self.bitmaps, sel, gcount, rid, perm=src, k_inj=kd, rng=self.rng)
+        ops.row_select(self.bitmaps, sel, gcount, rid, perm=src, k_inj=kd, rng=self.rng, cntblk=self.cntblk)
         out = torch.empty(n, self.Dd, device=d)
         ops.row_gather(self.table, rid, out, self.Dd)
         ops.state_advance(self.rng)
@@ -112,7 +117,7 @@ class DataSampler(object):
         permd = torch.as_tensor(np.asarray(perm, dtype=np.int64)).to(d)
         kd = torch.as_tensor(np.asarray(k, dtype=np.int64)).to(d) if k is not None else None
         rid = torch.empty(B, dtype=torch.int64, device=d)
-        ops.row_select(self.bitmaps, sel, gcount, rid, perm=permd, k_inj=kd, rng=self.rng)
+        ops.row_select(self.bitmaps, sel, gcount, rid, perm=permd, k_inj=kd, rng=self.rng, cntblk=self.cntblk)
         out = torch.empty(B, self.Dd, device=d)
         ops.row_gather(self.table, rid, out, self.Dd)
         ops.state_advance(self.rng)

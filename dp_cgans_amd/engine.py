@@ -316,7 +316,7 @@ class StepEngine(object):
             else:
                 ops.random_perm(self.rng, self.perm, self.keys_ws)
             ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
-                           rng=self.rng)
+                           rng=self.rng, cntblk=s.cntblk)
             ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
 
     def _gen_forward(self):

@@ -133,9 +133,11 @@ def build_bitmaps(table, cat_col, bitmaps):
     return bitmaps
 
 
-def cooccurrence(bitmaps, cnt):
+def cooccurrence(bitmaps, cnt, cntblk=None):
     C, W = bitmaps.shape
-    lib().call('dpc_cooccurrence', _p(bitmaps), W, C, _p(cnt), _stream())
+    _chk(cntblk, torch.int32, 'cntblk')
+    S = cntblk.shape[2] if cntblk is not None else 1
+    lib().call('dpc_cooccurrence', _p(bitmaps), W, C, _p(cnt), _p(cntblk), S, _stream())
     return cnt
 
 
@@ -153,11 +155,13 @@ def condvec_pair_sample(cnt, cond_st, dims, N, B, cond_dsts, mask, pair_id, val_
                _p(gcount), _stream())
 
 
-def row_select(bitmaps, sel, gcount, row_id, perm=None, k_inj=None, rng=None, site=SITE_ROWPICK):
+def row_select(bitmaps, sel, gcount, row_id, perm=None, k_inj=None, rng=None, site=SITE_ROWPICK, cntblk=None):
     _chk(perm, torch.int64, 'perm')
     _chk(k_inj, torch.int64, 'k_inj')
+    _chk(cntblk, torch.int32, 'cntblk')
+    C, S = (cntblk.shape[0], cntblk.shape[2]) if cntblk is not None else (0, 1)
     lib().call('dpc_row_select', _p(bitmaps), bitmaps.shape[1], _p(sel), _p(gcount), _p(perm), _p(k_inj), _p(rng), site,
-               row_id.shape[0], _p(row_id), _stream())
+               row_id.shape[0], _p(row_id), _p(cntblk), C, S, _stream())
     return row_id
 
 

@@ -89,7 +89,10 @@ int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc
  * category, cnt[C][C] co-occurrence counts.  cat_col[a] = encoded-matrix column of category a. */
 int dpc_build_bitmaps(const float* table, int64_t ld, int64_t N, const int32_t* cat_col, int C,
                       uint64_t* bitmaps, int64_t W, void* stream);
-int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, void* stream);
+/* cntblk (nullable) int32 [C][C][S]: cnt[a][b] split over S (1..64) superblocks of ceil(W/S) bitmap
+ * words; it lets dpc_row_select scan one superblock instead of the whole bitmaps. */
+int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, int32_t* cntblk, int S,
+                     void* stream);
 /* sample_condvec_pair (data_sampler.py:245-343).  pairs_inj int32 [B][2] = the ordered draw of
  * np.random.choice(nd, 2, replace=False); r_inj fp64 [B] = np.random.rand(B).  Writes cond to up
  * to three destinations, mask int32, pair_id / val_idx int64, and for the row pick: sel int32
@@ -104,7 +107,7 @@ int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const in
  * categories are sel[perm ? perm[b] : b]; k = k_inj[b] or floor(u * gcount).  -1 for an empty group. */
 int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,
                    const int64_t* perm, const int64_t* k_inj, const uint64_t* rng, uint32_t site,
-                   int64_t B, int64_t* row_id, void* stream);
+                   int64_t B, int64_t* row_id, const int32_t* cntblk, int C, int S, void* stream);
 /* tables without discrete columns (data_sampler.py:388-390): row_id[b] = floor(u_b * N) */
 int dpc_row_uniform(int64_t N, const double* u_inj, const uint64_t* rng, uint32_t site, int64_t B,
                     int64_t* row_id, void* stream);

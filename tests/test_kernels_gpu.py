@@ -496,3 +496,55 @@ def test_gemm_kscale_is_the_clip_scale_sum(ops):
         close(out, ref, what='kscale gemm %d' % rows)
     with pytest.raises(RuntimeError):
         ops.gemm(dl.to(dev()), dl.to(dev()), torch.empty(96, 96, device=dev()), trans_b=True, kscale=c.to(dev()))
+
+
+@pytest.mark.parametrize('N,S_expected', [(5000, 4), (70001, 64)])
+def test_row_select_superblocks_exact_on_synthetic_table(ops, N, S_expected):
+    """k-th matching row through the superblock counts == numpy's nonzero()[k] == the full-scan path."""
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.synthetic import schema_span_info
+    g = np.random.default_rng(N)
+    span = schema_span_info('TINY')                      # 4 continuous + 5 categorical -> 23 binary discrete columns
+    Dd = int(span[:, 0].sum())
+    enc = np.zeros((N, Dd), dtype=np.float32)
+    col = 0
+    for j in range(4):
+        m = 1 + j % 3
+        enc[:, col] = g.uniform(-0.9, 0.9, N)
+        enc[np.arange(N), col + 1 + g.integers(m, size=N)] = 1
+        col += 1 + m
+    for j in range(5):
+        k = [2, 3, 4, 6, 8][j]
+        p = 1.0 / np.arange(1, k + 1)
+        codes = g.choice(k, size=N, p=p / p.sum())
+        for v in range(k):
+            enc[:, col] = codes == v
+            enc[:, col + 1] = codes != v
+            col += 2
+    ds = DataSampler(enc, span, device=dev(), seed=1)
+    assert ds.cntblk is not None and ds.cntblk.shape[2] == S_expected
+    assert torch.equal(ds.cntblk.sum(2, dtype=torch.int64).int(), ds.cnt)
+    onehot = enc[:, ds.cat_col.cpu().numpy()] != 0
+    assert np.array_equal(ds.cnt.cpu().numpy(), (onehot.T.astype(np.int64) @ onehot.astype(np.int64)).astype(np.int32))
+    B = 4096
+    cond, mask, pid, vid = ds.sample_condvec_pair(B)
+    sel, gcount = ds._last_sel[0].cpu().numpy(), ds._last_sel[1].cpu().numpy()
+    u = g.random(B)
+    perm = g.permutation(B)
+    gp = gcount[perm]                                    # request b asks for a row of group perm[b]
+    k = np.minimum((u * gp).astype(np.int64), gp - 1)
+    k[0], k[1] = 0, gp[1] - 1                            # first and last member of a group
+    rid, rows = ds.rows_for(perm, k=k)
+    for b in range(B):
+        ca, cb = sel[perm[b]]
+        match = np.nonzero(onehot[:, ca] & onehot[:, cb])[0]
+        assert len(match) == gcount[perm[b]] and rid[b] == match[k[b]], b
+    assert np.array_equal(rows, enc[rid])
+    full = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.row_select(ds.bitmaps, ds._last_sel[0], ds._last_sel[1], full, perm=torch.from_numpy(perm).to(dev()),
+                   k_inj=torch.from_numpy(k).to(dev()))
+    assert np.array_equal(full.cpu().numpy(), rid)
+    bad = torch.full((3,), 7, dtype=torch.int64, device=dev())
+    ops.row_select(ds.bitmaps, ds._last_sel[0], ds._last_sel[1], bad, k_inj=torch.tensor([-1, 1 << 40, 0], device=dev()),
+                   cntblk=ds.cntblk)
+    assert bad[0].item() == -1 and bad[1].item() == -1 and bad[2].item() >= 0
