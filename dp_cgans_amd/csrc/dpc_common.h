@@ -66,7 +66,10 @@ __device__ __forceinline__ DpcPhilox4 dpc_philox(uint64_t seed, uint64_t step, u
 
 __device__ __forceinline__ uint32_t dpc_draw_u32(const uint64_t* rng, uint32_t site, uint64_t idx) {
   DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 2);
-  return p.v[idx & 3];
+  // selects, not p.v[idx & 3]: a dynamically indexed private array lives in scratch memory
+  const uint32_t l = (uint32_t)idx & 3u;
+  uint32_t lo = (l & 1u) ? p.v[1] : p.v[0], hi = (l & 1u) ? p.v[3] : p.v[2];
+  return (l & 2u) ? hi : lo;
 }
 
 // (0,1) open interval, 23 bits: k + 0.5 for k < 2^23 is exact in fp32, so neither 0 nor 1 can come
@@ -82,8 +85,8 @@ __device__ __forceinline__ double dpc_u64_to_unit(uint32_t hi, uint32_t lo) {
 // Standard normal number idx of (site, step): Box-Muller on draws 2*idx, 2*idx+1.
 __device__ __forceinline__ float dpc_draw_normal(const uint64_t* rng, uint32_t site, uint64_t idx) {
   DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 1);
-  int h = (int)(idx & 1) * 2;
-  float u1 = dpc_u32_to_unit(p.v[h]), u2 = dpc_u32_to_unit(p.v[h + 1]);
+  const bool h = (idx & 1) != 0;
+  float u1 = dpc_u32_to_unit(h ? p.v[2] : p.v[0]), u2 = dpc_u32_to_unit(h ? p.v[3] : p.v[1]);
   return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
 }
 

@@ -8,15 +8,17 @@
 //   input    dx = dy W    A = dy (k contiguous)   B = W[k,n]                      (n contiguous)
 //   weight   dW = dy^T x  A = dy viewed (m, k) -> dy[k,m] (m contiguous)   B = x[k,n] (n contiguous)
 //
-// Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 or 64x64), BK = 16,
-// operands staged global -> registers -> LDS as [k][m|n] images (k-major so that the 32 lanes of an
-// MFMA operand read consecutive dwords: conflict-free ds_read_b32), two LDS buffers, next tile's
-// global loads issued before the current tile's MFMAs (one barrier per K-tile).  Split-K over
+// Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 or 64x64), BK = 32,
+// operands staged global -> registers -> LDS (image per operand layout: see Stage), two LDS buffers,
+// the global loads of tile t+PF issued before the MFMAs of tile t (one barrier per K-tile).  Split-K over
 // gridDim.y with fp32 atomics for the weight-gradient shapes (small MxN, K = batch).  Block ids
 // are remapped so that the blocks sharing an A row-panel run on one XCD (private L2).
 #include "dpc_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native vector type for the staging registers: HIP's float4 is a struct whose copies lower to
+// llvm.memcpy between address spaces, which kept the prefetch ring in scratch memory
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define EPI_NONE 0
 #define EPI_LEAKY_DROPOUT 1
@@ -42,15 +44,21 @@ struct GemmArgs {
   const float* kscale;   // optional: A(m,k) *= kscale[k] (fused clip-scale-sum; m-contiguous A only)
 };
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
+// One operand's staging of a BMN x BK tile: global -> registers (float4) -> LDS.
+//   KC  (k contiguous in global: stride_mn = leading dimension): LDS image [mn][BK + 4].  A thread
+//       moves 4 consecutive k of one row with one 16-byte load and one ds_write_b128; a lane reads
+//       its MFMA operands for FOUR k-steps with one ds_read_b128.  Row stride 36 floats: any 16
+//       rows the hardware groups for a b128 access land on 16 different 4-bank sets (conflict-free).
+//   !KC (m/n contiguous: stride_k = leading dimension): LDS image [BK][mn + 4]; 16-byte stores,
+//       ds_read_b32 fragments (32 consecutive m/n per half-wave: conflict-free).
 template <int BMN, bool KC, bool KS = false>
 struct Stage {
-  // KC: operand is k-contiguous in global memory (stride_mn = leading dimension, stride_k = 1).
-  // !KC: operand is m/n-contiguous (stride_k = leading dimension).
-  static constexpr int PASSES = BMN / 64;
-  static constexpr int LD = BMN + (KC ? 2 : 4);
-  float4 r[PASSES];
+  static constexpr int PASSES = BMN / 32;
+  static constexpr int LD = KC ? (BK + 4) : (BMN + 4);
+  static constexpr int SIZE = KC ? BMN * (BK + 4) : BK * (BMN + 4);    // floats per LDS buffer
+  f32x4 r[PASSES];
   float sc[KS ? PASSES : 1];   // per-k scale of this thread's k-row (KS: m/n-contiguous operand only)
 
   // Fast path (block-uniform choice, see `fast` below): straight-line 16-byte loads with no
@@ -64,13 +72,13 @@ struct Stage {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       if (KC) {
-        int row = min(mn0 + p * 64 + (t >> 2), MN - 1);
-        r[p] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + 4 * (t & 3));
+        int row = min(mn0 + p * 32 + (t >> 3), MN - 1);
+        r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + k0 + 4 * (t & 7));
       } else {
         constexpr int TPR = BMN / 4;
         constexpr int RPP = 256 / TPR;
         int mn = min(mn0 + 4 * (t % TPR), ((MN + 3) & ~3) - 4);
-        r[p] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
+        r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
         if (KS) sc[p] = ks[k0 + p * RPP + t / TPR];
       }
     }
@@ -90,8 +98,8 @@ struct Stage {
     for (int p = 0; p < PASSES; ++p) {
       float e[4];
       if (KC) {
-        int row = mn0 + p * 64 + (t >> 2);
-        int k = k0 + 4 * (t & 3);
+        int row = mn0 + p * 32 + (t >> 3);
+        int k = k0 + 4 * (t & 7);
         const float* src = base + (int64_t)min(row, mlast) * ld;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -111,7 +119,7 @@ struct Stage {
         }
         if (KS) sc[p] = ks[min(k, klast)];
       }
-      r[p] = make_float4(e[0], e[1], e[2], e[3]);
+      r[p] = f32x4{e[0], e[1], e[2], e[3]};
     }
   }
 
@@ -120,34 +128,43 @@ struct Stage {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       if (KC) {
-        int row = p * 64 + (t >> 2);
-        int kq = 4 * (t & 3);
-        s[(kq + 0) * LD + row] = r[p].x;
-        s[(kq + 1) * LD + row] = r[p].y;
-        s[(kq + 2) * LD + row] = r[p].z;
-        s[(kq + 3) * LD + row] = r[p].w;
+        *reinterpret_cast<f32x4*>(&s[(p * 32 + (t >> 3)) * LD + 4 * (t & 7)]) = r[p];
       } else {
         constexpr int TPR = BMN / 4;
         constexpr int RPP = 256 / TPR;
         int krow = p * RPP + t / TPR;
-        float4 v = r[p];
-        if (KS) { v.x *= sc[p]; v.y *= sc[p]; v.z *= sc[p]; v.w *= sc[p]; }
-        *reinterpret_cast<float4*>(&s[krow * LD + 4 * (t % TPR)]) = v;
+        f32x4 v = r[p];
+        if (KS) v *= sc[p];
+        *reinterpret_cast<f32x4*>(&s[krow * LD + 4 * (t % TPR)]) = v;
       }
+    }
+  }
+
+  // MFMA operands of the 32-row slab starting at mn for the 8 k-steps kb .. kb+7: lane half h
+  // supplies k = kb + 4h + j to the j-th of four v_mfma_f32_32x32x2_f32 (any assignment of the 8
+  // k's to the 4 x 2 operand slots is a valid product as long as A and B use the same one).
+  __device__ static __forceinline__ void frag(const float* __restrict__ s, int mn, int kb, int li, int lk, float f[4]) {
+    if (KC) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&s[(mn + li) * LD + kb + 4 * lk]);
+      f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = s[(kb + 4 * lk + j) * LD + mn + li];
     }
   }
 };
 
+// 256 threads = 4 waves as 2 x 2 over a BM x BN block tile; each wave owns TM x TN 32x32 MFMA tiles.
 template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   static_assert(!(KS && A_KC), "kscale needs an m-contiguous A");
+  static_assert(PF == 2, "two register stages");
   using SA = Stage<BM, A_KC, KS>;
   using SB = Stage<BN, B_KC>;
-  constexpr int LDA = SA::LD, LDB = SB::LD;
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDA + 2 * BK * LDB];
+  __shared__ __attribute__((aligned(16))) float lds[2 * SA::SIZE + 2 * SB::SIZE];
   float* As = lds;
-  float* Bs = lds + 2 * BK * LDA;
+  float* Bs = lds + 2 * SA::SIZE;
 
   // XCD-aware remap (bijective for any grid size): ids congruent mod 8 share an XCD, give each
   // XCD a contiguous run of tiles so neighbours along N reuse the same A panel from one L2.
@@ -184,103 +201,120 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // (ld >= extent rounded up to 4) for the last 16-byte load to stay inside its row
   const bool fa = g.a_vec && (A_KC ? g.M >= 1 : (m0 + BM <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
   const bool fb = g.b_vec && (B_KC ? g.N >= 1 : (n0 + BN <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
-  SA sa[PF];
-  SB sb[PF];
+  // Two register stages per operand, as named objects (an array of stages indexed by the unrolled
+  // tile number made hipcc keep part of the ring in scratch memory).
+  SA sa0, sa1;
+  SB sb0, sb1;
   const int ntile = (k_end - k_begin + BK - 1) / BK;
   const int nfull = (fa && fb) ? (k_end - k_begin) / BK : 0;
-  const int nmain = (nfull / PF) * PF;
+  const int nmain = nfull & ~1;
+  float* const As0 = As;
+  float* const As1 = As + SA::SIZE;
+  float* const Bs0 = Bs;
+  float* const Bs1 = Bs + SB::SIZE;
 
   auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+    for (int kb = 0; kb < BK; kb += 8) {
+      float a[TM][4], b[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + lk) * LDA + wm0 + i * 32 + li];
+      for (int i = 0; i < TM; ++i) SA::frag(as, wm0 + i * 32, kb, li, lk, a[i]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lk) * LDB + wn0 + j * 32 + li];
+      for (int j = 0; j < TN; ++j) SB::frag(bs, wn0 + j * 32, kb, li, lk, b[j]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   };
 
-  // Main pipeline: nmain full K-tiles, strictly branch-free inside (loads past the end are clamped
-  // to the last tile, stores are unconditional), so hipcc keeps PF-1 tiles of loads in flight with
-  // counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow join.
+  // Main pipeline: nmain (even) full K-tiles, strictly branch-free inside (loads past the end are
+  // clamped to the last tile, stores are unconditional), so hipcc keeps a tile of loads in flight
+  // with counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow join.  The
+  // loads of tile t+2 are issued before the MFMAs of tile t and land in LDS one iteration later.
   if (nmain > 0) {
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M, g.kscale);
-      sb[j].load_fast(g.B, ldb, n0, k_begin + j * BK, g.N);
-    }
-    sa[0].store(As);
-    sb[0].store(Bs);
+    sa0.load_fast(g.A, lda, m0, k_begin, g.M, g.kscale);
+    sb0.load_fast(g.B, ldb, n0, k_begin, g.N);
+    sa1.load_fast(g.A, lda, m0, k_begin + BK, g.M, g.kscale);
+    sb1.load_fast(g.B, ldb, n0, k_begin + BK, g.N);
+    sa0.store(As0);
+    sb0.store(Bs0);
     __syncthreads();
-    for (int t0 = 0; t0 < nmain; t0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int cur = u & 1;              // PF is even, so t & 1 == u & 1
-        const int tl = min(t0 + u + PF, nmain - 1);
-        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
-        sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
-        compute(As + cur * BK * LDA, Bs + cur * BK * LDB);
-        sa[(u + 1) % PF].store(As + (cur ^ 1) * BK * LDA);
-        sb[(u + 1) % PF].store(Bs + (cur ^ 1) * BK * LDB);
-        __syncthreads();
-      }
+    for (int t0 = 0; t0 < nmain; t0 += 2) {
+      int tl = min(t0 + 2, nmain - 1);
+      sa0.load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
+      sb0.load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
+      compute(As0, Bs0);
+      sa1.store(As1);
+      sb1.store(Bs1);
+      __syncthreads();
+      tl = min(t0 + 3, nmain - 1);
+      sa1.load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
+      sb1.load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
+      compute(As1, Bs1);
+      sa0.store(As0);
+      sb0.store(Bs0);
+      __syncthreads();
     }
   }
-  // Remainder (< PF full tiles, a partial last tile, or operands the fast path cannot take).
+  // Remainder (one odd full tile, a partial last tile, or operands the fast path cannot take).
   for (int t = nmain; t < ntile; ++t) {
-    sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
-    sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
-    sa[0].store(As);
-    sb[0].store(Bs);
+    sa0.load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
+    sb0.load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
+    sa0.store(As0);
+    sb0.store(Bs0);
     __syncthreads();
-    compute(As, Bs);
+    compute(As0, Bs0);
     __syncthreads();
   }
 
   // Epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn0 + j * 32 + li;
-      if (col >= g.N) continue;
+  // (One straight-line body per MFMA tile, no `continue`: a loop over the tiles that hipcc does not
+  // fully unroll indexes `acc` dynamically and moves all accumulators to scratch memory.)
+  auto tile_out = [&](const f32x16& av, const int row0, const int col) {
+    if (col < g.N) {
       const float bv = (g.bias && blockIdx.y == 0) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = g.alpha * acc[i][j][e] + bv;
-        float* cp = g.C + (int64_t)row * g.ldc + col;
-        if (g.splitk > 1) {
-          atomicAdd(cp, v);
-          continue;
-        }
-        if (g.epi == EPI_LEAKY_DROPOUT) {
-          float keep;
-          if (g.keep) {
-            keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+        const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row < g.M) {
+          float v = g.alpha * av[e] + bv;
+          float* cp = g.C + (int64_t)row * g.ldc + col;
+          if (g.splitk > 1) {
+            atomicAdd(cp, v);
           } else {
-            keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
+            if (g.epi == EPI_LEAKY_DROPOUT) {
+              float keep;
+              if (g.keep) {
+                keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+              } else {
+                keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
+              }
+              float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
+              g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+              v *= slope;
+            } else if (g.epi == EPI_MUL) {
+              v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+            } else if (g.epi == EPI_RELU) {
+              v = fmaxf(v, 0.f);
+            }
+            if (g.beta != 0.f) v += g.beta * (*cp);
+            *cp = v;
           }
-          float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
-          g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
-          v *= slope;
-        } else if (g.epi == EPI_MUL) {
-          v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
-        } else if (g.epi == EPI_RELU) {
-          v = fmaxf(v, 0.f);
         }
-        if (g.beta != 0.f) v += g.beta * (*cp);
-        *cp = v;
       }
     }
+  };
+  tile_out(acc[0][0], m0 + wm0, n0 + wn0 + li);
+  if constexpr (TN > 1) tile_out(acc[0][1], m0 + wm0, n0 + wn0 + 32 + li);
+  if constexpr (TM > 1) {
+    tile_out(acc[1][0], m0 + wm0 + 32, n0 + wn0 + li);
+    if constexpr (TN > 1) tile_out(acc[1][1], m0 + wm0 + 32, n0 + wn0 + 32 + li);
   }
+  static_assert(TM <= 2 && TN <= 2, "epilogue is written out for up to 2 x 2 MFMA tiles per wave");
 }
 
 // Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
@@ -307,9 +341,11 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
 }
 
 static int g_force_tile = 0;
-// Tuning / test hook: force the block tile (64 or 128; 0 = automatic choice).
+// Tuning / test hook: force the block tile: 0 = automatic, 64 = 64x64, 128 = 128x128,
+// 12864 = 128x64, 64128 = 64x128.
 extern "C" int dpc_gemm_config(int force_tile) {
-  if (force_tile != 0 && force_tile != 64 && force_tile != 128) return DPC_EINVAL;
+  if (force_tile != 0 && force_tile != 64 && force_tile != 128 && force_tile != 12864 && force_tile != 64128)
+    return DPC_EINVAL;
   g_force_tile = force_tile;
   return DPC_OK;
 }
@@ -358,12 +394,19 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
   g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-  // Tile choice: 128x128 only when it still yields at least two blocks per CU.
-  int64_t big = dpc_cdiv(M, 128) * dpc_cdiv(N, 128);
-  bool use_big = g_force_tile ? g_force_tile == 128 : big >= 512;
-  int bm = use_big ? 128 : 64;
+  // Tile choice (measured per shape with `tools/gemm_bench.py tiles`): the 128x128 tile reaches
+  // 120-130 TF/s (~80 % of the fp32 MFMA peak) once the grid holds >= 2 blocks per CU, but every
+  // GEMM of the T1M training step (M*N <= 8192*512) is faster on 64x64 tiles, whose 4x as many
+  // blocks fill the 256 CUs; 128x64 / 64x128 never won there and are kept for forced use only.
+  int bm = 64, bn = 64;
+  if (g_force_tile) {
+    bm = (g_force_tile == 128 || g_force_tile == 12864) ? 128 : 64;
+    bn = (g_force_tile == 128 || g_force_tile == 64128) ? 128 : 64;
+  } else if (dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512) {
+    bm = 128; bn = 128;
+  }
   g.tiles_m = (int)dpc_cdiv(M, bm);
-  g.tiles_n = (int)dpc_cdiv(N, bm);
+  g.tiles_n = (int)dpc_cdiv(N, bn);
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
   bool deferred_epi = false;
   if (splitk <= 0) {
@@ -394,8 +437,10 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   }
   GemmArgs full = g;
   if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; }
-  if (use_big) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
-  else launch_tile<64, 64, 4>(g, a_kc, b_kc, st);
+  if (bm == 128 && bn == 128) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
+  else if (bm == 128) launch_tile<128, 64, 2>(g, a_kc, b_kc, st);
+  else if (bn == 128) launch_tile<64, 128, 2>(g, a_kc, b_kc, st);
+  else launch_tile<64, 64, 2>(g, a_kc, b_kc, st);
   if (deferred_epi)
     hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(dpc_grid((int64_t)M * N, 256)), dim3(256), 0, st, full);
   DPC_LAUNCH_CHECK();

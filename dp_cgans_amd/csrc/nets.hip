@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColArgs a) {
   if (f < a.F) {
     float mu = 0.f, is = 0.f;
     if (MODE == 2) { mu = a.mean[f]; is = a.invstd[f]; }
+    // unrolled so that 8 independent row loads are in flight per thread (the sums are cheap; what
+    // bounds this kernel is load latency at 1-2 blocks per CU)
+#pragma unroll 8
     for (int64_t r = r0 + rl; r < r1; r += 4) {
       float v = a.x[r * a.ldx + f];
       if (MODE == 0) {
@@ -63,9 +66,8 @@ static int pick_R(int64_t rows, int F, int max_R) {
   // enough row chunks to spread the reduction over the chip, at least 256 rows per chunk; the
   // finish kernel walks the chunks serially, so keep them few
   int64_t colblocks = dpc_cdiv(F, 64);
-  int64_t R = dpc_cdiv(256, colblocks);
-  if (R > 32) R = 32;
-  int64_t cap = dpc_cdiv(rows, 256);
+  int64_t R = dpc_cdiv(512, colblocks);
+  int64_t cap = dpc_cdiv(rows, 64);
   if (R > cap) R = cap;
   if (R > max_R) R = max_R;
   if (R < 1) R = 1;
@@ -102,9 +104,15 @@ __global__ __launch_bounds__(256) void colreduce_finish_kernel(const double* __r
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
   double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s0 += part[((int64_t)r * nout + 0) * F + f];
-    if (nout == 2) s1 += part[((int64_t)r * nout + 1) * F + f];
+  if (nout == 2) {
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) {
+      s0 += part[((int64_t)r * 2 + 0) * F + f];
+      s1 += part[((int64_t)r * 2 + 1) * F + f];
+    }
+  } else {
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) s0 += part[(int64_t)r * F + f];
   }
   if (kind == 0) {
     double mean = s0 / count;
@@ -130,7 +138,7 @@ extern "C" int dpc_colreduce_finish(const double* part, int R, int nout, int F, 
   DPC_CHECK_ARG(R >= 1 && (nout == 1 || nout == 2) && F > 0 && kind >= 0 && kind <= 2, "colreduce_finish: bad argument");
   DPC_CHECK_ARG(nout == 1 || out1, "colreduce_finish: second output missing");
   DPC_CHECK_ARG(kind != 0 || (nout == 2 && count > 0.0), "colreduce_finish: statistics need two sums and a count");
-  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, part,
                      R, nout, F, kind, count, eps, momentum, out0, out1, run_mean, run_var, accumulate);
   DPC_LAUNCH_CHECK();
   return DPC_OK;

@@ -60,7 +60,8 @@ int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep, const uint64_t* rng,
                  uint32_t site, float leak, int splitk, const float* kscale, void* stream);
 
-/* tuning / test hook: force the GEMM block tile (64, 128; 0 = automatic).  Host-side state. */
+/* tuning / test hook: force the GEMM block tile (0 automatic, 64 = 64x64, 128 = 128x128,
+ * 12864 = 128x64, 64128 = 64x128).  Host-side state. */
 int dpc_gemm_config(int force_tile);
 
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
