@@ -193,6 +193,14 @@ class StepEngine(object):
         self.losses = torch.zeros(4, **f32)          # loss_d, pen, -mean(y_fake), cond loss
         maxF = max(self.gdim + self.ddim + [self.Dd, 1])
         self.part = torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64)
+        # Independent kernels of a step (the real-row sampling chain beside the generator forward, the
+        # weight-gradient GEMMs beside the input-gradient chain) run on side streams; inside a captured
+        # graph that becomes parallel branches, which fill CUs that one small GEMM leaves idle.  Each
+        # side stream has its own reduction workspace.
+        self.side = [torch.cuda.Stream(device=d) for _ in range(2)] if self.dev.type == 'cuda' else []
+        self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
+        self._open = []          # side streams with work the main stream has not joined yet
+        self.concurrent = True
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
         self.cond = torch.zeros(B, max(self.C, 1), **f32)
         self.mask = torch.zeros(B, max(self.nd, 1), device=d, dtype=torch.int32)
@@ -306,18 +314,19 @@ class StepEngine(object):
         if not need_real:
             return
         real = self.Xd[B:2 * B]
-        if 'real' in inj:
-            real[:, :Dd].copy_(inj['real'])
-            real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else self.cond[inj['perm']])
-        else:
-            s = self.sampler
-            if 'perm' in inj:
-                self.perm.copy_(inj['perm'])
+        with self._fork(0):      # beside the generator forward; joined before the interpolation
+            if 'real' in inj:
+                real[:, :Dd].copy_(inj['real'])
+                real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else self.cond[inj['perm']])
             else:
-                ops.random_perm(self.rng, self.perm, self.keys_ws)
-            ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
-                           rng=self.rng, cntblk=s.cntblk)
-            ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
+                s = self.sampler
+                if 'perm' in inj:
+                    self.perm.copy_(inj['perm'])
+                else:
+                    ops.random_perm(self.rng, self.perm, self.keys_ws)
+                ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
+                               rng=self.rng, cntblk=s.cntblk)
+                ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
 
     def _gen_forward(self):
         g = self.gen
@@ -362,6 +371,7 @@ class StepEngine(object):
         (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
         inj = inj or {}
         self._draw_inputs(inj, need_real=True)
+        self._join()
         self._disc_forward(self.n, inj, row0=self.n)
         ops.state_advance(self.rng)
         return self.y[self.n:2 * self.n].detach().cpu().view(-1, 1)
@@ -374,17 +384,53 @@ class StepEngine(object):
             ops.gemm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
                      aux_in=self.S[i - 1][0:rows])
 
+    class _Fork(object):
+        """``with eng._fork(k):`` runs the block on side stream k after everything issued so far on
+        the main stream; ``eng._join()`` makes the main stream wait for all open side streams."""
+
+        def __init__(self, eng, k):
+            self.eng, self.k = eng, k
+
+        def __enter__(self):
+            e = self.eng
+            if not e.concurrent or not e.side:
+                self.ctx = None
+                return e.part
+            side = e.side[self.k]
+            side.wait_stream(torch.cuda.current_stream(e.dev))
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            if side not in e._open:
+                e._open.append(side)
+            return e.part_side[self.k]
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            return False
+
+    def _fork(self, k):
+        return StepEngine._Fork(self, k)
+
+    def _join(self):
+        main = torch.cuda.current_stream(self.dev)
+        for side in self._open:
+            main.wait_stream(side)
+        self._open = []
+
     def _allreduce(self, t):
         if self.dist.world == 1:
             return t
+        self._join()             # a collective (and a graph cut) needs every branch back on the main stream
         if self._ar_hook is not None:      # graph capture in progress: the collective runs between graph segments
             self._ar_hook(t)
             return t
         return self.dist.allreduce(t)
 
-    def _colsum(self, x, out, w=None, accumulate=False):
-        R = ops.colreduce_partial(1, x, self.part, w=w)
-        ops.colreduce_finish(self.part, R, 1, x.shape[1], 1, out, accumulate=accumulate)
+    def _colsum(self, x, out, w=None, accumulate=False, part=None):
+        part = self.part if part is None else part
+        R = ops.colreduce_partial(1, x, part, w=w)
+        ops.colreduce_finish(part, R, 1, x.shape[1], 1, out, accumulate=accumulate)
 
     # ------------------------------------------------------------------------------------------
     # discriminator update
@@ -395,6 +441,7 @@ class StepEngine(object):
         self._draw_inputs(inj, need_real=True)
         self._gen_forward()
         self._activate(inj)
+        self._join()
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
                         rng=self.rng)
         self._disc_forward(3 * n, inj)
@@ -424,14 +471,20 @@ class StepEngine(object):
             ops.clip_factors(self.norm2, self.dp_clip, float(self.gn), self.rowc, roww=self.rowscale_d,
                              rowc_w=self.rowc_w, norm_out=self.norms)
             kscale, w_last, w_bias = self.rowc, self.rowc_w, self.rowc[0:2 * n]
-        prev = self.Xd3
-        for i in range(M):
-            # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
-            ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
-            self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1), w=w_bias)
-            prev = self.H[i]
-        self._colsum(prev, d.G('seq.%d.weight' % (3 * M)), w=w_last)
-        self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=w_last[0:2 * n])
+        # weight gradients: the first layer's product (K0 wide) on the main stream, everything else beside it
+        with self._fork(0) as part:
+            prev = self.H[0]
+            for i in range(1, M):
+                ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
+                self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1), w=w_bias, part=part)
+                prev = self.H[i]
+        with self._fork(1) as part:
+            self._colsum(self.H[M - 1], d.G('seq.%d.weight' % (3 * M)), w=w_last, part=part)
+            self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=w_last[0:2 * n], part=part)
+            self._colsum(self.Dl[0][0:2 * n], d.G('seq.0.bias').view(1, -1), w=w_bias, part=part)
+        # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
+        ops.gemm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
+        self._join()
         if update:
             self._disc_update(inj)
         ops.state_advance(self.rng)
@@ -478,11 +531,13 @@ class StepEngine(object):
         else:
             self.dfake.copy_(self.dX)
             self.losses[3:4].zero_()
-        # generator backward
+        # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
+        # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
-        ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True)
-        self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1))
+        with self._fork(0) as part:
+            ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True)
+            self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1), part=part)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
         count = float(self.gB)
@@ -496,11 +551,13 @@ class StepEngine(object):
             ops.bn_relu_bwd(dy, yv, self.Z[l], self.bn_mean[l], self.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
                             dgamma, count, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
-            ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True)
-            self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1))
+            with self._fork((L - l) % 2) as part:
+                ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True)
+                self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1), part=part)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
                 ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
+        self._join()
         if update:
             self._gen_update()
         ops.state_advance(self.rng)
