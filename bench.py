@@ -67,9 +67,7 @@ def main():
     setup_s = time.time() - t0
 
     def eager_step():
-        for _ in range(args.d_steps):
-            eng.d_step()
-        eng.g_step()
+        eng.train_step(args.d_steps)
 
     gstep = GraphStep(eng, args.d_steps)
     step = eager_step if args.no_graph else gstep.run

@@ -131,20 +131,21 @@ extern "C" int dpc_clip_factors(const double* norm2, int64_t n, float clip, floa
 // The reference's private-mode hook noise (dp_cgan.py:638-647): every hook firing adds
 // one scalar N(0,1)/B to the whole gradient tensor, and after t discriminator steps a tensor
 // carries t+1 hook sets, each fired `fires[s]` times per step.  The sum of those independent
-// scalars is N(0, fires[s]*(t+1)) / B:  seg_add[s] = z_s * sqrt(fires[s] * (t+1)) * inv_B.
-__global__ void hook_noise_kernel(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
-                                  const uint64_t* rng, uint32_t site) {
+// scalars is N(0, fires[s]*(t+1)) / B:  seg_add[s] = z_s * sqrt(fires[s] * (t + t_add)) * inv_B
+// (t = *t_dev discriminator updates done before this step, t_add = 1 + updates done inside it).
+__global__ void hook_noise_kernel(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, int t_add,
+                                  float inv_B, const uint64_t* rng, uint32_t site) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nseg) return;
-  float t1 = (float)(t_dev[0] + 1);
+  float t1 = (float)(t_dev[0] + t_add);
   seg_add[s] = dpc_draw_normal(rng, site, (uint64_t)s) * sqrtf(fires[s] * t1) * inv_B;
 }
 
-extern "C" int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
-                              const uint64_t* rng, uint32_t site, void* stream) {
-  DPC_CHECK_ARG(seg_add && fires && t_dev && rng && nseg > 0, "hook_noise: bad argument");
+extern "C" int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, int t_add,
+                              float inv_B, const uint64_t* rng, uint32_t site, void* stream) {
+  DPC_CHECK_ARG(seg_add && fires && t_dev && rng && nseg > 0 && t_add >= 1, "hook_noise: bad argument");
   hipLaunchKernelGGL(hook_noise_kernel, dim3((unsigned)dpc_cdiv(nseg, 64)), dim3(64), 0, (hipStream_t)stream, seg_add,
-                     nseg, fires, t_dev, inv_B, rng, site);
+                     nseg, fires, t_dev, t_add, inv_B, rng, site);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -11,18 +11,22 @@ extern "C" void dpc_set_error(const char* msg) {
 extern "C" const char* dpc_last_error(void) { return g_err; }
 extern "C" int dpc_version(void) { return 100; }
 
-__global__ void rng_advance_kernel(uint64_t* rng, int32_t* t_a, int32_t* t_b) {
+__global__ void rng_advance_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* t_a, int add_a, int32_t* t_b, int add_b) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    if (rng) rng[1] += 1;
-    if (t_a) t_a[0] += 1;
-    if (t_b) t_b[0] += 1;
+    if (rng_a) rng_a[1] += 1;
+    if (rng_b) rng_b[1] += 1;
+    if (t_a) t_a[0] += add_a;
+    if (t_b) t_b[0] += add_b;
   }
 }
 
-// Bump the RNG step counter and up to two optimiser step counters (device-resident so that a
-// captured graph replays with fresh numbers).  Any pointer may be null.
-extern "C" int dpc_state_advance(uint64_t* rng, int32_t* t_a, int32_t* t_b, void* stream) {
-  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng, t_a, t_b);
+// End-of-step bookkeeping in ONE launch: bump the step counter of up to two RNG states and add to up
+// to two optimiser step counters (all device-resident so that a captured graph replays with fresh
+// numbers).  Any pointer may be null.  Must run after every kernel of the step that reads them.
+extern "C" int dpc_state_advance(uint64_t* rng_a, uint64_t* rng_b, int32_t* t_a, int add_a, int32_t* t_b, int add_b,
+                                 void* stream) {
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_a, rng_b, t_a, add_a, t_b,
+                     add_b);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -84,7 +88,7 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
-    int t = a.t_dev ? a.t_dev[0] + 1 : a.t_host;
+    int t = (a.t_dev ? a.t_dev[0] : 0) + a.t_host;
     bc[0] = (float)(a.lr / (1.0 - pow((double)a.b1, (double)t)));
     bc[1] = (float)sqrt(1.0 - pow((double)a.b2, (double)t));
   }
@@ -118,7 +122,7 @@ extern "C" int dpc_adam_step(float* p, const float* g, float* m, float* v, int64
                              void* stream) {
   DPC_CHECK_ARG(p && g && m && v, "adam: null pointer");
   DPC_CHECK_ARG(n >= 0, "adam: negative size");
-  DPC_CHECK_ARG(t_dev || t_host >= 1, "adam: step count must be >= 1");
+  DPC_CHECK_ARG(t_host >= 1, "adam: step count offset must be >= 1");
   DPC_CHECK_ARG(nseg == 0 || (seg_off && seg_add), "adam: segment table missing");
   DPC_CHECK_ARG(noise_scale == 0.f || noise_inj || rng, "adam: noise requested without a source");
   if (n == 0) return DPC_OK;

@@ -312,56 +312,52 @@ extern "C" int dpc_row_gather(const float* table, int64_t ld, const int64_t* row
   return DPC_OK;
 }
 
-// Uniform random permutation of 0..B-1 by ranking 64-bit Philox keys (ties broken by index).
-__global__ __launch_bounds__(256) void perm_keys_kernel(const uint64_t* rng, uint32_t site, int64_t B, uint64_t* keys,
-                                                        unsigned long long* ranks) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) {
-    keys[i] = ((uint64_t)dpc_draw_u32(rng, site, 2 * (uint64_t)i) << 32) | dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1);
-    ranks[i] = 0;
+// Random permutation of 0..B-1 (np.random.shuffle(arange(B)), dp_cgan.py:594-595, in distribution)
+// without sorting: perm[i] = P(i) for a keyed bijection P of [0, 2^bits) restricted to [0, B) by
+// cycle walking.  P is a 6-round Feistel network over the (a | b)-bit halves of i whose round
+// functions are Philox words of this (seed, step, site); every element is independent (one thread
+// each, O(B) work, one launch; ranking 64-bit keys cost O(B^2) compares and three launches).
+// Cycle walking ends: the orbit of i under P returns to i < B.
+__device__ __forceinline__ uint32_t dpc_feistel(uint32_t x, int abits, int bbits, const uint64_t* rng, uint32_t site) {
+  const uint32_t amask = (1u << abits) - 1u, bmask = (1u << bbits) - 1u;
+  uint32_t L = x >> bbits, R = x & bmask;                 // L: abits, R: bbits
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    // round r mixes the half that is currently R into L; halves swap (and trade widths) every round
+    uint32_t f = dpc_draw_u32(rng, site, ((uint64_t)r << 34) | ((uint64_t)R << 2));
+    if ((r & 1) == 0) {
+      uint32_t nl = R, nr = (L ^ f) & amask;               // new halves: (bbits | abits)
+      L = nl; R = nr;
+    } else {
+      uint32_t nl = R, nr = (L ^ f) & bmask;               // back to (abits | bbits)
+      L = nl; R = nr;
+    }
   }
+  return (L << bbits) | R;                                  // 6 rounds: widths are (abits | bbits) again
 }
-// grid (ceil(B/256), ceil(B/1024)): block (x, y) counts, for its 256 keys, how many of the y-th
-// 1024 keys sort before them; integer atomics, so the result does not depend on arrival order.
-__global__ __launch_bounds__(256) void perm_count_kernel(const uint64_t* __restrict__ keys, int64_t B,
-                                                         unsigned long long* __restrict__ ranks) {
-  __shared__ __attribute__((aligned(16))) uint64_t tile[1024];
+
+__global__ __launch_bounds__(256) void perm_feistel_kernel(const uint64_t* rng, uint32_t site, int64_t B, int abits,
+                                                           int bbits, int64_t* __restrict__ perm) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t j0 = (int64_t)blockIdx.y * 1024;
-  for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < B) ? keys[j0 + q] : ~0ull;
-  __syncthreads();
   if (i >= B) return;
-  uint64_t ki = keys[i];
-  int lim = (int)min((int64_t)1024, B - j0);
-  unsigned cnt = 0;
-  // keys past the end are ~0 (never below a real key; equal only to a real ~0 key, where the index
-  // tie-break keeps them out), so the loop runs over the whole tile with 16-byte LDS reads
-  (void)lim;
-  const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile);
-#pragma unroll 8
-  for (int j = 0; j < 512; ++j) {
-    ulonglong2 kk = t2[j];
-    cnt += (kk.x < ki) || (kk.x == ki && (j0 + 2 * j) < i);
-    cnt += (kk.y < ki) || (kk.y == ki && (j0 + 2 * j + 1) < i);
-  }
-  if (cnt) atomicAdd(&ranks[i], (unsigned long long)cnt);
-}
-__global__ __launch_bounds__(256) void perm_scatter_kernel(const unsigned long long* __restrict__ ranks, int64_t B,
-                                                           int64_t* __restrict__ perm) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) perm[ranks[i]] = i;
+  uint32_t x = (uint32_t)i;
+  do {
+    x = dpc_feistel(x, abits, bbits, rng, site);
+  } while ((int64_t)x >= B);
+  perm[i] = (int64_t)x;
 }
 
 extern "C" int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
                                void* stream) {
-  DPC_CHECK_ARG(rng && perm && keys_ws && B >= 0, "random_perm: bad argument");
+  (void)keys_ws;                                            // (workspace of the former sort-based version)
+  DPC_CHECK_ARG(rng && perm && B >= 0, "random_perm: bad argument");
+  DPC_CHECK_ARG(B <= (1LL << 30), "random_perm: at most 2^30 elements");
   if (B == 0) return DPC_OK;
-  hipStream_t st = (hipStream_t)stream;
-  unsigned gx = (unsigned)dpc_cdiv(B, 256), gy = (unsigned)dpc_cdiv(B, 1024);
-  unsigned long long* ranks = (unsigned long long*)(keys_ws + B);
-  hipLaunchKernelGGL(perm_keys_kernel, dim3(gx), dim3(256), 0, st, rng, site, B, keys_ws, ranks);
-  hipLaunchKernelGGL(perm_count_kernel, dim3(gx, gy), dim3(256), 0, st, keys_ws, B, ranks);
-  hipLaunchKernelGGL(perm_scatter_kernel, dim3(gx), dim3(256), 0, st, ranks, B, perm);
+  int bits = 2;
+  while ((1LL << bits) < B) ++bits;
+  int abits = bits / 2, bbits = bits - abits;
+  hipLaunchKernelGGL(perm_feistel_kernel, dim3((unsigned)dpc_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, rng, site,
+                     B, abits, bbits, perm);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -200,6 +200,7 @@ class StepEngine(object):
         self.side = [torch.cuda.Stream(device=d) for _ in range(2)] if self.dev.type == 'cuda' else []
         self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
         self._open = []          # side streams with work the main stream has not joined yet
+        self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
         self.cond = torch.zeros(B, max(self.C, 1), **f32)
@@ -290,14 +291,15 @@ class StepEngine(object):
         if 'z' in inj:
             zv.copy_(inj['z'])
         else:
-            ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
+            ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z + self._so, 0.0, 1.0)
         if not self.has_cond:
             if need_real:     # uniform rows (data_sampler.py:388-390)
                 real = self.Xd[B:2 * B]
                 if 'real' in inj:
                     real.copy_(inj['real'])
                 else:
-                    ops.row_uniform(self.sampler.N, self.row_id, u_inj=inj.get('u_row'), rng=self.rng)
+                    ops.row_uniform(self.sampler.N, self.row_id, u_inj=inj.get('u_row'), rng=self.rng,
+                                    site=ops.SITE_ROWPICK + self._so)
                     ops.row_gather(self.sampler.table, self.row_id, real, Dd)
             return
         fake_c = self.Xd[0:B, Dd:]
@@ -310,7 +312,7 @@ class StepEngine(object):
             s = self.sampler
             ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [self.cond, cv, fake_c], self.mask, self.pair_id,
                                     self.val_idx, self.sel, self.gcount, pairs_inj=inj.get('pairs'),
-                                    r_inj=inj.get('r'), rng=self.rng)
+                                    r_inj=inj.get('r'), rng=self.rng, site=ops.SITE_CONDVEC + self._so)
         if not need_real:
             return
         real = self.Xd[B:2 * B]
@@ -323,9 +325,9 @@ class StepEngine(object):
                 if 'perm' in inj:
                     self.perm.copy_(inj['perm'])
                 else:
-                    ops.random_perm(self.rng, self.perm, self.keys_ws)
+                    ops.random_perm(self.rng, self.perm, self.keys_ws, site=ops.SITE_PERM + self._so)
                 ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
-                               rng=self.rng, cntblk=s.cntblk)
+                               rng=self.rng, cntblk=s.cntblk, site=ops.SITE_ROWPICK + self._so)
                 ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
 
     def _gen_forward(self):
@@ -348,10 +350,12 @@ class StepEngine(object):
     def _activate(self, inj):
         dst = self.Xd[0:self.B, :self.Dd] if self.has_cond else self.Xd[0:self.B]
         if self.has_cond:
-            ops.apply_activate_fwd(self.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng)
+            ops.apply_activate_fwd(self.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
+                                   site=ops.SITE_GUMBEL + self._so)
         else:
             # no discrete columns: both networks see the raw generator output (dp_cgan.py:624-626, Q5)
-            ops.apply_activate_fwd(self.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng)
+            ops.apply_activate_fwd(self.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
+                                   site=ops.SITE_GUMBEL + self._so)
             dst.copy_(self.fake)
 
     def _disc_forward(self, rows, inj, row0=0):
@@ -362,7 +366,7 @@ class StepEngine(object):
         for i in range(self.M):
             ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
-                     rng=self.rng, site=ops.SITE_DROP0 + i, leak=LEAK)
+                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
             x = self.H[i][rs]
         ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * self.M)), d.P('seq.%d.bias' % (3 * self.M)), self.y[rs])
 
@@ -370,6 +374,7 @@ class StepEngine(object):
         """Discriminator output on a freshly sampled batch of real rows with their cond vectors
         (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
         inj = inj or {}
+        self._so = 0
         self._draw_inputs(inj, need_real=True)
         self._join()
         self._disc_forward(self.n, inj, row0=self.n)
@@ -435,15 +440,20 @@ class StepEngine(object):
     # ------------------------------------------------------------------------------------------
     # discriminator update
     # ------------------------------------------------------------------------------------------
-    def d_step(self, inj=None, update=True):
+    def d_step(self, inj=None, update=True, sub=None):
+        """One discriminator update.  Stand-alone (``sub`` None) it ends by advancing the RNG / Adam
+        step counters itself; inside ``train_step`` it is update number ``sub`` of the step, draws
+        from call sites offset by 64*sub and leaves the single end-of-step advance to the caller."""
         inj = inj or {}
+        self._so = 0 if sub is None else 64 * sub
+        self._k = 0 if sub is None else sub
         n, B, M, d = self.n, self.B, self.M, self.disc
         self._draw_inputs(inj, need_real=True)
         self._gen_forward()
         self._activate(inj)
         self._join()
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
-                        rng=self.rng)
+                        rng=self.rng, site=ops.SITE_ALPHA + self._so)
         self._disc_forward(3 * n, inj)
         ops.mean_pair(self.y, n, n / self.gn, -n / self.gn, self.losses[0:1])      # this rank's share of the global means
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
@@ -487,7 +497,8 @@ class StepEngine(object):
         self._join()
         if update:
             self._disc_update(inj)
-        ops.state_advance(self.rng)
+        if sub is None:
+            ops.state_advance(self.rng, rng_b=self.rng_shared if update else None, t_a=self.disc.t if update else None)
 
     def _disc_update(self, inj):
         d = self.disc
@@ -499,7 +510,8 @@ class StepEngine(object):
             if 'hook_noise' in inj:
                 self.hook_add.copy_(inj['hook_noise'])
             else:
-                ops.hook_noise(self.hook_add, self.hook_fires, d.t, 1.0 / self.gB, self.rng_shared)
+                ops.hook_noise(self.hook_add, self.hook_fires, d.t, 1.0 / self.gB, self.rng_shared,
+                               site=ops.SITE_HOOK + self._so, t_add=1 + self._k)
             seg_add, seg_off = self.hook_add, d.seg_off
         elif self.dp_mode == 'dpsgd':
             # the gradient buffer holds (1/n) sum_i clip(g_i); one N(0, (sigma*C)^2) draw per
@@ -507,16 +519,19 @@ class StepEngine(object):
             noise_scale = self.dp_sigma * self.dp_clip / self.gn
             noise_inj = inj.get('dp_noise')
         ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=self.weight_clip if self.private else 0.0,
-                      t_dev=d.t, seg_off=seg_off, seg_add=seg_add, noise_scale=noise_scale, noise_inj=noise_inj,
-                      rng=self.rng_shared, site=ops.SITE_NOISE_D)
-        ops.state_advance(self.rng_shared, t_a=d.t)
+                      t_dev=d.t, t_host=1 + self._k, seg_off=seg_off, seg_add=seg_add, noise_scale=noise_scale,
+                      noise_inj=noise_inj, rng=self.rng_shared, site=ops.SITE_NOISE_D + self._so)
 
     # ------------------------------------------------------------------------------------------
     # generator update
     # ------------------------------------------------------------------------------------------
-    def g_step(self, inj=None, update=True):
+    def g_step(self, inj=None, update=True, sub=None):
+        """One generator update (``sub``: see d_step)."""
         inj = inj or {}
+        self._so = 0 if sub is None else 64 * sub
+        self._k = 0
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
+        g.g.zero_()          # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
         self._draw_inputs(inj, need_real=False)
         self._gen_forward()
         self._activate(inj)
@@ -536,7 +551,7 @@ class StepEngine(object):
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
         with self._fork(0) as part:
-            ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True)
+            ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True, beta=1.0)
             self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1), part=part)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
@@ -552,7 +567,7 @@ class StepEngine(object):
                             dgamma, count, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
             with self._fork((L - l) % 2) as part:
-                ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True)
+                ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True, beta=1.0)
                 self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1), part=part)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
@@ -560,7 +575,8 @@ class StepEngine(object):
         self._join()
         if update:
             self._gen_update()
-        ops.state_advance(self.rng)
+        if sub is None:
+            ops.state_advance(self.rng, t_a=self.gen.t if update else None)
 
     def _gen_update(self):
         g = self.gen
@@ -572,12 +588,21 @@ class StepEngine(object):
                 g.G('seq.%d.bn.bias' % l).mul_(1.0 / self.dist.world)
         self._allreduce(g.g)
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
-        ops.state_advance(t_a=g.t)
+
+    def train_step(self, d_steps=1):
+        """``d_steps`` discriminator updates and one generator update (one iteration of the
+        reference's loop, dp_cgan.py:570-722), then ONE launch that advances both RNG step counters
+        and both Adam step counters."""
+        for k in range(d_steps):
+            self.d_step(sub=k)
+        self.g_step(sub=d_steps)
+        ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
 
     # ------------------------------------------------------------------------------------------
     def sample_forward(self, cond=None):
         """Generator forward + activation for DPCGANSynthesizer.sample (BatchNorm in training mode,
         as the reference never calls .eval(): dp_cgan.py:881, Q2).  Returns the activated batch."""
+        self._so = 0
         zv, cv = self._zc()
         ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
         if self.has_cond:
@@ -606,9 +631,7 @@ class GraphStep(object):
         self._stream = None
 
     def _body(self):
-        for _ in range(self.d_steps):
-            self.eng.d_step()
-        self.eng.g_step()
+        self.eng.train_step(self.d_steps)
 
     def capture(self):
         eng = self.eng

@@ -55,8 +55,8 @@ def new_rng(seed, device):
     return torch.tensor([seed & 0x7fffffffffffffff, 0], dtype=torch.int64, device=device)
 
 
-def state_advance(rng=None, t_a=None, t_b=None):
-    lib().call('dpc_state_advance', _p(rng), _p(t_a), _p(t_b), _stream())
+def state_advance(rng=None, t_a=None, t_b=None, rng_b=None, add_a=1, add_b=1):
+    lib().call('dpc_state_advance', _p(rng), _p(rng_b), _p(t_a), int(add_a), _p(t_b), int(add_b), _stream())
 
 
 def fill(out, kind, rng, site, a=0.0, b=1.0):
@@ -278,6 +278,6 @@ def clip_factors(norm2, clip, gscale, rowc, roww=None, rowc_w=None, norm_out=Non
                _p(norm_out), _stream())
 
 
-def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK):
-    lib().call('dpc_hook_noise', _p(seg_add), seg_add.shape[0], _p(fires), _p(t_dev), float(inv_B), _p(rng), site,
-               _stream())
+def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK, t_add=1):
+    lib().call('dpc_hook_noise', _p(seg_add), seg_add.shape[0], _p(fires), _p(t_dev), int(t_add), float(inv_B), _p(rng),
+               site, _stream())

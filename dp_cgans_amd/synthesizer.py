@@ -188,9 +188,7 @@ class DPCGANSynthesizer(object):
                 if gstep is not None:
                     gstep.run()
                 else:
-                    for _ in range(self._discriminator_steps):
-                        eng.d_step()
-                    eng.g_step()
+                    eng.train_step(self._discriminator_steps)
             losses = eng.global_losses()              # one sync per epoch, as the reference's .item() (dp_cgan.py:735-736)
             generator_loss = float(losses[2] + losses[3])
             discriminator_loss = float(losses[0])

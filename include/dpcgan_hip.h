@@ -34,9 +34,11 @@ int dpc_version(void);
 const char* dpc_last_error(void);
 
 /* ---- random state / fills -------------------------------------------------------------- */
-/* rng[1] += 1, *t_a += 1, *t_b += 1 (any may be NULL).  No reference counterpart: the reference
- * uses the global torch / numpy generators (dp_cgan.py:581, data_sampler.py:211,269). */
-int dpc_state_advance(uint64_t* rng, int32_t* t_a, int32_t* t_b, void* stream);
+/* End-of-step bookkeeping in one launch: rng_a[1] += 1, rng_b[1] += 1, *t_a += add_a, *t_b += add_b
+ * (any pointer may be NULL).  No reference counterpart: the reference uses the global torch / numpy
+ * generators (dp_cgan.py:581, data_sampler.py:211,269) and torch.optim's host step counters. */
+int dpc_state_advance(uint64_t* rng_a, uint64_t* rng_b, int32_t* t_a, int add_a, int32_t* t_b, int add_b,
+                      void* stream);
 
 /* out[r*ld + c] = draw(r*cols + c).  kind: 0 u32, 1 normal(a, b) f32 (torch.normal,
  * dp_cgan.py:581,673), 2 Exp(1) f32 (Tensor.exponential_ inside F.gumbel_softmax, :307),
@@ -117,7 +119,8 @@ int dpc_row_uniform(int64_t N, const double* u_inj, const uint64_t* rng, uint32_
 int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd,
                    float* out, int64_t ldo, const int32_t* sel, const int64_t* perm, int C,
                    void* stream);
-/* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution; keys_ws: 2*B uint64. */
+/* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution: a keyed Feistel bijection of
+ * [0, 2^bits) cycle-walked into [0, B); keys_ws is unused (kept for ABI stability, may be NULL). */
 int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
                     void* stream);
 
@@ -170,7 +173,7 @@ int dpc_mean_pair(const float* y, int64_t n, float sa, float sb, float* out, int
 
 /* ---- gradient post-processing + optimiser (dp_cgan.py:510-518, 638-661) ---------------------- */
 /* One launch over a flat parameter buffer: g_eff = gscale*g + seg_add[segment] + noise_scale*noise,
- * coupled-L2 Adam, optional clamp to +-clamp.  t = *t_dev + 1 when t_dev != NULL else t_host.
+ * coupled-L2 Adam, optional clamp to +-clamp.  Step count t = (t_dev ? *t_dev : 0) + t_host, t_host >= 1.
  * seg_off int64 [nseg+1] device, seg_add fp32 [nseg] device (the reference's per-tensor scalar
  * hook noise); noise_inj fp32 [n] or Philox normal idx i. */
 int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
@@ -192,9 +195,9 @@ int dpc_persample_gram(const float* delta, int64_t ldd, int d, const float* act,
  * (nullable), norm_out[i] = gscale*sqrt(norm2[i]) (nullable). */
 int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,
                      const float* roww, float* rowc_w, float* norm_out, void* stream);
-/* Reference private mode (dp_cgan.py:638-647): seg_add[s] = N(0,1)_s * sqrt(fires[s]*(t+1)) * inv_B,
- * the sum of the scalar noises that (t+1) accumulated hook sets add to parameter tensor s. */
-int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, float inv_B,
+/* Reference private mode (dp_cgan.py:638-647): seg_add[s] = N(0,1)_s * sqrt(fires[s]*(*t_dev + t_add)) * inv_B,
+ * the sum of the scalar noises that the accumulated hook sets add to parameter tensor s. */
+int dpc_hook_noise(float* seg_add, int nseg, const float* fires, const int32_t* t_dev, int t_add, float inv_B,
                    const uint64_t* rng, uint32_t site, void* stream);
 
 #ifdef __cplusplus

@@ -92,8 +92,7 @@ def graph(dist, dev, mode):
         return eng
     a, b = make(), make()
     for _ in range(4):
-        a.d_step()
-        a.g_step()
+        a.train_step(1)
     gs = GraphStep(b, d_steps=1)
     for _ in range(4):
         gs.run()

@@ -287,9 +287,7 @@ def test_graph_replay_equals_eager_steps(mode):
     a, b = make(), make()
     steps = 5
     for _ in range(steps):
-        a.d_step()
-        a.d_step()
-        a.g_step()
+        a.train_step(2)
     gs = GraphStep(b, d_steps=2)
     for _ in range(steps):
         gs.run()

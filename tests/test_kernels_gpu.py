@@ -548,3 +548,27 @@ def test_row_select_superblocks_exact_on_synthetic_table(ops, N, S_expected):
     ops.row_select(ds.bitmaps, ds._last_sel[0], ds._last_sel[1], bad, k_inj=torch.tensor([-1, 1 << 40, 0], device=dev()),
                    cntblk=ds.cntblk)
     assert bad[0].item() == -1 and bad[1].item() == -1 and bad[2].item() >= 0
+
+
+@pytest.mark.parametrize('B', [1, 2, 5, 64, 100, 8192, 10007])
+def test_random_perm_is_a_permutation_and_looks_uniform(ops, B):
+    """Feistel / cycle-walking permutation: a bijection of 0..B-1 for every size; for small B the value
+    at each position is uniform over many steps (chi-square against the uniform law)."""
+    rng = ops.new_rng(123, dev())
+    perm = torch.empty(B, dtype=torch.int64, device=dev())
+    ops.random_perm(rng, perm, None)
+    assert torch.equal(torch.sort(perm).values, torch.arange(B, device=dev()))
+    if B == 64:
+        T = 4000
+        counts = np.zeros((B, B))
+        fixed = 0
+        for _ in range(T):
+            ops.state_advance(rng)
+            ops.random_perm(rng, perm, None)
+            p = perm.cpu().numpy()
+            counts[np.arange(B), p] += 1
+            fixed += int((p == np.arange(B)).sum())
+        chi2 = ((counts - T / B) ** 2 / (T / B)).sum()
+        dof = (B - 1) ** 2
+        assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof), chi2          # within 6 sigma of the chi-square mean
+        assert abs(fixed / T - 1.0) < 0.15                             # a uniform permutation has 1 fixed point on average
