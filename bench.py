@@ -106,9 +106,11 @@ def main():
         ops.GEMM_PROFILE = []
         nprof = min(args.steps, 20)
         if dist.world == 1:
+            eng.concurrent = False       # one stream: every GEMM's events bracket that GEMM alone
             for _ in range(nprof):
                 eager_step()
             torch.cuda.synchronize()
+            eng.concurrent = True
             prof = ops.GEMM_PROFILE
             ops.GEMM_PROFILE = None
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)

@@ -53,8 +53,10 @@ __device__ __forceinline__ DpcPhilox4 dpc_philox(uint64_t seed, uint64_t step, u
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // full 32x32 -> 64 products (one v_mad_u64_u32 each instead of a mul_hi + mul_lo pair)
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -82,12 +84,31 @@ __device__ __forceinline__ double dpc_u64_to_unit(uint32_t hi, uint32_t lo) {
   return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
 }
 
-// Standard normal number idx of (site, step): Box-Muller on draws 2*idx, 2*idx+1.
+// Standard normals: Philox block b of (site, step) yields normals 4b .. 4b+3 by Box-Muller on its
+// word pairs (v0, v1) and (v2, v3), cosine and sine branch each, on the hardware transcendental
+// units (v_log_f32 is log2, v_sin/v_cos take revolutions): sqrt(-2 ln u1) = sqrt(-2 ln2 * log2 u1).
+// One Philox call and eight quarter-rate instructions per four normals keeps the DP noise kernels
+// HBM-bound instead of VALU-bound.  |z| <= 5.77 (u1 >= 2^-24).
+__device__ __forceinline__ void dpc_box_muller(uint32_t a, uint32_t b, float& zc, float& zs) {
+  float u1 = dpc_u32_to_unit(a), u2 = dpc_u32_to_unit(b);
+  float r = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u1));
+  zc = r * __builtin_amdgcn_cosf(u2);
+  zs = r * __builtin_amdgcn_sinf(u2);
+}
+
+__device__ __forceinline__ void dpc_normal4(const uint64_t* rng, uint32_t site, uint64_t blk, float z[4]) {
+  DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, blk);
+  dpc_box_muller(p.v[0], p.v[1], z[0], z[1]);
+  dpc_box_muller(p.v[2], p.v[3], z[2], z[3]);
+}
+
+// Normal number idx (one element of dpc_normal4's block idx >> 2).
 __device__ __forceinline__ float dpc_draw_normal(const uint64_t* rng, uint32_t site, uint64_t idx) {
-  DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 1);
-  const bool h = (idx & 1) != 0;
-  float u1 = dpc_u32_to_unit(h ? p.v[2] : p.v[0]), u2 = dpc_u32_to_unit(h ? p.v[3] : p.v[1]);
-  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+  DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, idx >> 2);
+  const bool hi = (idx & 2) != 0;
+  float zc, zs;
+  dpc_box_muller(hi ? p.v[2] : p.v[0], hi ? p.v[3] : p.v[1], zc, zs);
+  return (idx & 1) ? zs : zc;
 }
 
 // ---------------------------------------------------------------------------------------------

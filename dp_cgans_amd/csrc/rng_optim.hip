@@ -34,19 +34,38 @@ extern "C" int dpc_state_advance(uint64_t* rng_a, uint64_t* rng_b, int32_t* t_a,
 // kind: 0 raw u32 (as float bits are NOT used; written to uint32 out), 1 normal f32, 2 Exp(1) f32,
 //       3 uniform(0,1) f32, 4 uniform [0,1) f64 (two draws: 2*idx, 2*idx+1), 5 keep bit (u8)
 template <int KIND, typename T>
-__global__ void fill_kernel(T* out, int64_t ld, int64_t rows, int64_t cols, const uint64_t* rng, uint32_t site,
-                            float a, float b) {
-  int64_t n = rows * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i / cols, c = i - r * cols;
-    T v;
-    if (KIND == 0) v = (T)dpc_draw_u32(rng, site, (uint64_t)i);
-    else if (KIND == 1) v = (T)(a + b * dpc_draw_normal(rng, site, (uint64_t)i));
-    else if (KIND == 2) v = (T)(-logf(dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)i))));
-    else if (KIND == 3) v = (T)dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)i));
-    else if (KIND == 4) v = (T)dpc_u64_to_unit(dpc_draw_u32(rng, site, 2 * (uint64_t)i), dpc_draw_u32(rng, site, 2 * (uint64_t)i + 1));
-    else v = (T)(dpc_draw_u32(rng, site, (uint64_t)i) >> 31);
-    out[r * ld + c] = v;
+__global__ __launch_bounds__(256) void fill_kernel(T* out, int64_t ld, int64_t rows, int64_t cols, const uint64_t* rng,
+                                                   uint32_t site, float a, float b) {
+  // one thread per group of draws that share a Philox block: 4 consecutive flat indices (2 for the
+  // fp64 uniforms, which take two words each)
+  constexpr int PER = (KIND == 4) ? 2 : 4;
+  const int64_t n = rows * cols, ngrp = (n + PER - 1) / PER;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < ngrp; q += (int64_t)gridDim.x * blockDim.x) {
+    T v[PER];
+    if (KIND == 1) {
+      float z[4];
+      dpc_normal4(rng, site, (uint64_t)q, z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (T)(a + b * z[j]);
+    } else {
+      DpcPhilox4 p = dpc_philox(rng[0], rng[1], site, (uint64_t)q);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (KIND == 0) v[j] = (T)p.v[j];
+        else if (KIND == 2) v[j] = (T)(-logf(dpc_u32_to_unit(p.v[j])));
+        else if (KIND == 3) v[j] = (T)dpc_u32_to_unit(p.v[j]);
+        else if (KIND == 4) v[j] = (T)dpc_u64_to_unit(p.v[2 * j], p.v[2 * j + 1]);
+        else v[j] = (T)(p.v[j] >> 31);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int64_t i = q * PER + j;
+      if (i < n) {
+        int64_t r = i / cols, c = i - r * cols;
+        out[r * ld + c] = v[j];
+      }
+    }
   }
 }
 
@@ -56,7 +75,7 @@ extern "C" int dpc_fill(void* out, int kind, int64_t ld, int64_t rows, int64_t c
   DPC_CHECK_ARG(rows >= 0 && cols >= 0 && ld >= cols, "fill: bad shape");
   if (rows * cols == 0) return DPC_OK;
   hipStream_t st = (hipStream_t)stream;
-  int grid = dpc_grid(rows * cols, 256);
+  int grid = dpc_grid((rows * cols + 3) / 4, 256);
   switch (kind) {
     case 0: hipLaunchKernelGGL((fill_kernel<0, uint32_t>), dim3(grid), dim3(256), 0, st, (uint32_t*)out, ld, rows, cols, rng, site, a, b); break;
     case 1: hipLaunchKernelGGL((fill_kernel<1, float>), dim3(grid), dim3(256), 0, st, (float*)out, ld, rows, cols, rng, site, a, b); break;
@@ -85,6 +104,27 @@ struct AdamArgs {
   float noise_scale; const float* noise_inj; const uint64_t* rng; uint32_t site;
 };
 
+__device__ __forceinline__ float adam_one(const AdamArgs& a, int64_t i, float g, float p, float& m, float& v,
+                                          float z, float step_size, float bc2s) {
+  g *= a.gscale;
+  if (a.nseg > 0) {
+    int s = 0;
+    while (s + 1 < a.nseg && i >= a.seg_off[s + 1]) ++s;
+    g += a.seg_add[s];
+  }
+  g += a.noise_scale * z;
+  g += a.wd * p;
+  m = m + (1.f - a.b1) * (g - m);
+  v = a.b2 * v + (1.f - a.b2) * g * g;
+  float denom = sqrtf(v) / bc2s + a.eps;
+  p -= step_size * (m / denom);
+  if (a.clamp > 0.f) p = fminf(fmaxf(p, -a.clamp), a.clamp);
+  return p;
+}
+
+// VEC: all four buffers (and the injected noise) are 16-byte aligned; each thread owns 4 consecutive
+// parameters = one Philox block of noise.
+template <bool VEC>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
@@ -95,23 +135,37 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __syncthreads();
   const float step_size = bc[0], bc2s = bc[1];
   const bool noisy = a.noise_scale != 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
-    float g = a.gscale * a.g[i];
-    if (a.nseg > 0) {
-      int s = 0;
-      while (s + 1 < a.nseg && i >= a.seg_off[s + 1]) ++s;
-      g += a.seg_add[s];
+  const int64_t nq = (a.n + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q << 2;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noisy && !a.noise_inj) dpc_normal4(a.rng, a.site, (uint64_t)q, z);
+    if (VEC && i0 + 4 <= a.n) {
+      float4 p = *reinterpret_cast<const float4*>(a.p + i0), g = *reinterpret_cast<const float4*>(a.g + i0);
+      float4 m = *reinterpret_cast<const float4*>(a.m + i0), v = *reinterpret_cast<const float4*>(a.v + i0);
+      if (noisy && a.noise_inj) {
+        float4 zi = *reinterpret_cast<const float4*>(a.noise_inj + i0);
+        z[0] = zi.x; z[1] = zi.y; z[2] = zi.z; z[3] = zi.w;
+      }
+      p.x = adam_one(a, i0 + 0, g.x, p.x, m.x, v.x, z[0], step_size, bc2s);
+      p.y = adam_one(a, i0 + 1, g.y, p.y, m.y, v.y, z[1], step_size, bc2s);
+      p.z = adam_one(a, i0 + 2, g.z, p.z, m.z, v.z, z[2], step_size, bc2s);
+      p.w = adam_one(a, i0 + 3, g.w, p.w, m.w, v.w, z[3], step_size, bc2s);
+      *reinterpret_cast<float4*>(a.p + i0) = p;
+      *reinterpret_cast<float4*>(a.m + i0) = m;
+      *reinterpret_cast<float4*>(a.v + i0) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t i = i0 + j;
+        if (i < a.n) {
+          float m = a.m[i], v = a.v[i];
+          float zz = (noisy && a.noise_inj) ? a.noise_inj[i] : z[j];
+          a.p[i] = adam_one(a, i, a.g[i], a.p[i], m, v, zz, step_size, bc2s);
+          a.m[i] = m; a.v[i] = v;
+        }
+      }
     }
-    if (noisy) g += a.noise_scale * (a.noise_inj ? a.noise_inj[i] : dpc_draw_normal(a.rng, a.site, (uint64_t)i));
-    float p = a.p[i];
-    g += a.wd * p;
-    float m = a.m[i];
-    m = m + (1.f - a.b1) * (g - m);
-    float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
-    float denom = sqrtf(v) / bc2s + a.eps;
-    p -= step_size * (m / denom);
-    if (a.clamp > 0.f) p = fminf(fmaxf(p, -a.clamp), a.clamp);
-    a.p[i] = p; a.m[i] = m; a.v[i] = v;
   }
 }
 
@@ -131,45 +185,49 @@ extern "C" int dpc_adam_step(float* p, const float* g, float* m, float* v, int64
   a.clamp = clamp; a.gscale = gscale; a.t_dev = t_dev; a.t_host = t_host; a.seg_off = seg_off;
   a.seg_add = seg_add; a.nseg = nseg; a.noise_scale = noise_scale; a.noise_inj = noise_inj; a.rng = rng;
   a.site = site;
-  hipLaunchKernelGGL(adam_kernel, dim3(dpc_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)noise_inj;
+  if ((al & 15) == 0) hipLaunchKernelGGL(adam_kernel<true>, dim3(dpc_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(adam_kernel<false>, dim3(dpc_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
 
 // Standalone DP noise-add (+ optional clamp) over a flat buffer: x = clamp(x + scale * noise).
 // 8 B/element of algorithmic HBM traffic (12 with an injected noise tensor).
+__device__ __forceinline__ float4 noise_clamp4(float4 v, const float z[4], float scale, float clamp) {
+  v.x += scale * z[0]; v.y += scale * z[1]; v.z += scale * z[2]; v.w += scale * z[3];
+  if (clamp > 0.f) {
+    v.x = fminf(fmaxf(v.x, -clamp), clamp); v.y = fminf(fmaxf(v.y, -clamp), clamp);
+    v.z = fminf(fmaxf(v.z, -clamp), clamp); v.w = fminf(fmaxf(v.w, -clamp), clamp);
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void noise_add_clamp_kernel(float* x, int64_t n, float scale, const float* inj,
                                                               const uint64_t* rng, uint32_t site, float clamp) {
-  int64_t n4 = n >> 2;
+  const int64_t n4 = n >> 2;
   float4* x4 = reinterpret_cast<float4*>(x);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  const float4* j4 = reinterpret_cast<const float4*>(inj);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // one quad per iteration: with 32 waves per CU resident the loads of other waves cover this one's
+  // Philox + Box-Muller (two quads in flight per thread measured 7 % slower: VALU-bound, not latency-bound)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 v = x4[i];
-    float z0, z1, z2, z3;
+    float z[4];
     if (inj) {
-      float4 q = reinterpret_cast<const float4*>(inj)[i];
-      z0 = q.x; z1 = q.y; z2 = q.z; z3 = q.w;
+      float4 q = j4[i];
+      z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
     } else {
-      // normals 4i..4i+3 = Box-Muller pairs of Philox blocks 2i and 2i+1 (same map as dpc_draw_normal)
-      DpcPhilox4 pa = dpc_philox(rng[0], rng[1], site, 2 * (uint64_t)i);
-      DpcPhilox4 pb = dpc_philox(rng[0], rng[1], site, 2 * (uint64_t)i + 1);
-      z0 = sqrtf(-2.f * logf(dpc_u32_to_unit(pa.v[0]))) * cospif(2.f * dpc_u32_to_unit(pa.v[1]));
-      z1 = sqrtf(-2.f * logf(dpc_u32_to_unit(pa.v[2]))) * cospif(2.f * dpc_u32_to_unit(pa.v[3]));
-      z2 = sqrtf(-2.f * logf(dpc_u32_to_unit(pb.v[0]))) * cospif(2.f * dpc_u32_to_unit(pb.v[1]));
-      z3 = sqrtf(-2.f * logf(dpc_u32_to_unit(pb.v[2]))) * cospif(2.f * dpc_u32_to_unit(pb.v[3]));
+      dpc_normal4(rng, site, (uint64_t)i, z);       // normals 4i .. 4i+3 (same map as dpc_draw_normal)
     }
-    v.x += scale * z0; v.y += scale * z1; v.z += scale * z2; v.w += scale * z3;
-    if (clamp > 0.f) {
-      v.x = fminf(fmaxf(v.x, -clamp), clamp); v.y = fminf(fmaxf(v.y, -clamp), clamp);
-      v.z = fminf(fmaxf(v.z, -clamp), clamp); v.w = fminf(fmaxf(v.w, -clamp), clamp);
-    }
-    x4[i] = v;
+    x4[i] = noise_clamp4(v, z, scale, clamp);
   }
-  // tail
-  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float z = inj ? inj[i] : dpc_draw_normal(rng, site, (uint64_t)i);
-    float v = x[i] + scale * z;
+  // tail (n % 4 elements)
+  for (int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    float z = inj ? inj[t] : dpc_draw_normal(rng, site, (uint64_t)t);
+    float v = x[t] + scale * z;
     if (clamp > 0.f) v = fminf(fmaxf(v, -clamp), clamp);
-    x[i] = v;
+    x[t] = v;
   }
 }
 
