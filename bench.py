@@ -116,9 +116,22 @@ def main():
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
             flops = sum(f for _, _, f, _ in prof)
             achieved = flops / (ms * 1e-3) / 1e12
+            alg_bytes = sum(4.0 * (m * k + k * n + m * n) for _, _, _, (m, n, k, _, _) in prof) / len(prof)
+            # HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of this workload
+            # (tools/pmc_traffic.py, gfx950 correction applied); only valid for the default workload
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')
+            default_wl = (args.table == 'T1M' and args.rows is None and args.batch == 8192 and args.pac == 8
+                          and args.dims == '256,256' and args.d_steps == 1 and args.dp_mode == 'dpsgd')
+            if default_wl and os.path.exists(tpath):
+                traffic = json.load(open(tpath))['traffic_bytes_per_launch']
             out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                               'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC passes)',
+                               'algorithmic_bytes_per_launch': alg_bytes,
                                'kernel': 'gemm_f32_kernel', 'launches_per_step': len(prof) / nprof,
+                               'gflop_per_launch': flops / len(prof) / 1e9,
+                               'avg_launch_us': 1e3 * ms / len(prof),
                                'gflop_per_step': flops / nprof / 1e9, 'gemm_ms_per_step': ms / nprof}
         ops.GEMM_PROFILE = None
         # DP noise/clamp kernel (HBM-bound): x = clamp(x + s*N(0,1)), 8 B/element algorithmic

@@ -172,7 +172,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   int bid = blockIdx.x;
   int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  int tile_m = wg / g.tiles_n, tile_n = wg - tile_m * g.tiles_n;
+  // consecutive ids (= one XCD's run) walk the SHORTER tile axis first, so the tiles that share a
+  // panel of the larger operand sit in one L2 (a weight gradient with 4 x 77 tiles used to fetch its
+  // 60 MB activation operand once per tile row: 2x the algorithmic HBM/MALL traffic by FETCH_SIZE)
+  int tile_m, tile_n;
+  if (g.tiles_m < g.tiles_n) { tile_n = wg / g.tiles_m; tile_m = wg - tile_n * g.tiles_m; }
+  else { tile_m = wg / g.tiles_n; tile_n = wg - tile_m * g.tiles_n; }
   int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int k_begin = blockIdx.y * g.kchunk;
