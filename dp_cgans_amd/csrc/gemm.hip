@@ -346,6 +346,14 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
 }
 
 static int g_force_tile = 0;
+static int g_deterministic = 0;
+// Reproducible mode: never split K automatically (split sums are fp32 atomics, whose arrival order
+// changes the last bits from run to run).  Host-side state.
+extern "C" int dpc_set_deterministic(int on) {
+  g_deterministic = on ? 1 : 0;
+  return DPC_OK;
+}
+
 // Tuning / test hook: force the block tile: 0 = automatic, 64 = 64x64, 128 = 128x128,
 // 12864 = 128x64, 64128 = 64x128.
 extern "C" int dpc_gemm_config(int force_tile) {
@@ -415,15 +423,25 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
   bool deferred_epi = false;
   if (splitk <= 0) {
-    // auto: split a long K when there are too few tiles to fill the chip.  Products with a bias /
-    // activation epilogue then run as plain split-K sums + one elementwise pass (beta must be 0).
+    // auto: pick the K split that minimises a small cost model fitted to MI355X measurements of the
+    // 64x64 tile (tools/gemm_bench.py): a block costs 3 us + 19.5 ns per k, the chip runs 256
+    // blocks side by side (what matters is how evenly the blocks spread over the CUs: 270 blocks
+    // take as long as 512), split sums pay fp32 atomics at ~1.3 TB/s plus a memset, and a bias /
+    // activation epilogue then needs its own elementwise pass.
     splitk = 1;
-    if ((beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && blocks < 128 && K >= 1024) {
-      int64_t s = dpc_cdiv(256, blocks);
+    const bool can_split = !g_deterministic && (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && bm == 64 && bn == 64 && K >= 512;
+    if (can_split) {
+      const bool deferred = (epi != EPI_NONE || bias);
+      double best = 1e30;
       int64_t maxs = K / 256;
-      if (s > maxs) s = maxs;
-      if (s > 32) s = 32;
-      if (s >= 2) splitk = (int)s;
+      if (maxs > 32) maxs = 32;
+      for (int64_t sp = 1; sp <= maxs; ++sp) {
+        double nb = (double)(blocks * sp);
+        double waves = nb <= 512.0 ? (double)dpc_cdiv((int64_t)nb, 256) : nb / 256.0 + 0.3;
+        double t = waves * ((double)K / sp * 0.0195 + 3.0);
+        if (sp > 1) t += (double)M * N * 4.0 * sp / 1.3e6 + (beta == 0.f ? 5.0 : 0.0) + (deferred ? 6.0 : 0.0);
+        if (t < best * 0.97) { best = t; splitk = (int)sp; }    // prefer the smaller split on near ties
+      }
     }
   }
   if (splitk > 1 && (epi != EPI_NONE || bias)) {

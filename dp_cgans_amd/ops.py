@@ -50,6 +50,11 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+def set_deterministic(on=True):
+    """Bit-reproducible steps (no split-K atomics in the GEMMs), at some cost in speed."""
+    lib().call('dpc_set_deterministic', int(bool(on)))
+
+
 def new_rng(seed, device):
     """Device-resident {seed, step} pair."""
     return torch.tensor([seed & 0x7fffffffffffffff, 0], dtype=torch.int64, device=device)

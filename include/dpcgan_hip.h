@@ -65,6 +65,9 @@ int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
 /* tuning / test hook: force the GEMM block tile (0 automatic, 64 = 64x64, 128 = 128x128,
  * 12864 = 128x64, 64128 = 64x128).  Host-side state. */
 int dpc_gemm_config(int force_tile);
+/* reproducible mode: no automatic split-K (its fp32 atomics make the last bits order-dependent);
+ * every other kernel of the library is bit-reproducible already.  Host-side state. */
+int dpc_set_deterministic(int on);
 
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
 /* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)

@@ -90,6 +90,8 @@ def graph(dist, dev, mode):
         eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=dist)
         eng.sampler = DataSampler(enc, span, device=dev, seed=9 + dist.rank)
         return eng
+    from dp_cgans_amd import ops as _ops
+    _ops.set_deterministic(True)      # bit-equality below needs the atomics-free GEMM path
     a, b = make(), make()
     for _ in range(4):
         a.train_step(1)

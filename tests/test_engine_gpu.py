@@ -284,6 +284,8 @@ def test_graph_replay_equals_eager_steps(mode):
         eng = StepEngine(span, 24, (40, 24), (48, 16), 120, 10, dev, private=True, dp_mode=mode, seed=3)
         eng.sampler = DataSampler(enc, span, device=dev, seed=9)
         return eng
+    from dp_cgans_amd import ops as _ops
+    _ops.set_deterministic(True)      # bit-equality below needs the atomics-free GEMM path
     a, b = make(), make()
     steps = 5
     for _ in range(steps):
@@ -297,3 +299,4 @@ def test_graph_replay_equals_eager_steps(mode):
     assert torch.equal(a.losses, b.losses)
     assert a.bn_batches == b.bn_batches == steps * 3
     assert torch.isfinite(a.disc.p).all() and torch.isfinite(a.gen.p).all()
+    _ops.set_deterministic(False)
