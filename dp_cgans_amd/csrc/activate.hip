@@ -151,8 +151,9 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
 extern "C" int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
                              int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
                              float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
-                             int n_partials, int64_t B_total, void* stream) {
-  DPC_CHECK_ARG(fake && cond && mask && col2d && col2c && loss_out && partials, "cond_loss: null pointer");
+                             int n_partials, int64_t B_total, int* n_used, void* stream) {
+  DPC_CHECK_ARG(fake && cond && mask && col2d && col2c && partials, "cond_loss: null pointer");
+  DPC_CHECK_ARG(loss_out || n_used, "cond_loss: neither a loss output nor a partial count requested");
   DPC_CHECK_ARG(B > 0 && Dd > 0 && nd > 0, "cond_loss: bad shape");
   DPC_CHECK_ARG(n_partials >= 1, "cond_loss: workspace too small");
   int grid = dpc_grid(B * Dd, 256);
@@ -162,7 +163,9 @@ extern "C" int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cond_loss_kernel, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d, col2c, B,
                      Dd, scale, dfake, lddf, accumulate, partials);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B_total * (double)nd), loss_out);
+  if (n_used) *n_used = grid;          // the caller may sum partials[0 : grid] * 2/(B_total*nd) later (dpc_sum_f64)
+  if (loss_out)
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B_total * (double)nd), loss_out);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -98,6 +98,89 @@ extern "C" int dpc_persample_gram(const float* delta, int64_t ldd, int d, const 
   return DPC_OK;
 }
 
+// All layers of the discriminator in one launch, clip factors included: block i walks the layers,
+// adds their Gram contractions and writes c_i (what dpc_persample_gram per layer + dpc_clip_factors
+// compute, in the same summation order).
+#define DPC_MAX_LAYERS 8
+struct GramAllArgs {
+  const float* delta[DPC_MAX_LAYERS]; int64_t ldd[DPC_MAX_LAYERS]; int d[DPC_MAX_LAYERS];
+  const float* act[DPC_MAX_LAYERS]; int64_t lda[DPC_MAX_LAYERS]; int K[DPC_MAX_LAYERS];
+  int vec_d[DPC_MAX_LAYERS], vec_a[DPC_MAX_LAYERS];
+  int nlayers; int64_t n;
+  float clip, gscale;
+  double* norm2; float* rowc; const float* roww; float* rowc_w; float* norm_out;
+};
+
+__global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) {
+  __shared__ double red[4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+    double total = 0.0;                                   // meaningful in thread 0 only
+    for (int l = 0; l < a.nlayers; ++l) {
+      float g[12];
+      const float* dl = a.delta[l];
+      const float* ac = a.act[l];
+      if (a.vec_d[l]) gram3_partial<true>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
+      else gram3_partial<false>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
+      if (a.vec_a[l]) gram3_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
+      else gram3_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
+      double s[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) s[q] = dpc_wave_sum((double)g[q]);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) red[wave][q] = s[q];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        double v = t[0] * t[6] + t[3] * t[9] + t[5] * t[11] + 2.0 * (t[1] * t[7] + t[2] * t[8] + t[4] * t[10]);
+        v += t[0] + 2.0 * t[1] + t[3];                     // bias: ||delta_0 + delta_1||^2
+        total += v;
+      }
+    }
+    if (threadIdx.x == 0) {
+      a.norm2[i] = total;
+      float nrm = a.gscale * (float)sqrt(total);
+      float c = nrm > a.clip ? a.clip / nrm : 1.f;
+      if (a.norm_out) a.norm_out[i] = nrm;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a.rowc[p * a.n + i] = c;
+        if (a.rowc_w) a.rowc_w[p * a.n + i] = c * a.roww[p * a.n + i];
+      }
+    }
+  }
+}
+
+// delta / act: host arrays of nlayers device pointers (each [3n, d_l] / [3n, K_l]) with their
+// leading dimensions and widths.  Every layer counts its bias.
+extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
+                                      const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
+                                      float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
+                                      float* norm_out, void* stream) {
+  DPC_CHECK_ARG(nlayers >= 1 && nlayers <= DPC_MAX_LAYERS, "persample_clip_all: 1..8 layers");
+  DPC_CHECK_ARG(delta && ldd && d && act && lda && K && norm2 && rowc && n > 0, "persample_clip_all: null pointer");
+  DPC_CHECK_ARG(clip > 0.f && gscale > 0.f, "persample_clip_all: clip bound and scale must be positive");
+  DPC_CHECK_ARG(!rowc_w || roww, "persample_clip_all: row weights missing");
+  GramAllArgs a;
+  for (int l = 0; l < nlayers; ++l) {
+    DPC_CHECK_ARG(delta[l] && act[l] && d[l] > 0 && K[l] > 0 && ldd[l] >= d[l] && lda[l] >= K[l], "persample_clip_all: bad layer");
+    a.delta[l] = delta[l]; a.ldd[l] = ldd[l]; a.d[l] = d[l]; a.act[l] = act[l]; a.lda[l] = lda[l]; a.K[l] = K[l];
+    a.vec_d[l] = (((uintptr_t)delta[l] & 15) == 0) && (ldd[l] % 4 == 0) && (d[l] % 4 == 0);
+    a.vec_a[l] = (((uintptr_t)act[l] & 15) == 0) && (lda[l] % 4 == 0) && (K[l] % 4 == 0);
+  }
+  a.nlayers = nlayers; a.n = n; a.clip = clip; a.gscale = gscale; a.norm2 = norm2; a.rowc = rowc; a.roww = roww;
+  a.rowc_w = rowc_w; a.norm_out = norm_out;
+  hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
 // c_i = min(1, clip / (gscale * sqrt(norm2[i]))); rowc[p*n + i] = c_i for the three rows of example i
 // (the per-row scale handed to the weight-gradient GEMM and the bias column sums), and
 // rowc_w[r] = rowc[r] * roww[r] (the head layer's row weights).  norm_out[i] = gscale*sqrt(norm2[i]).

@@ -202,25 +202,37 @@ extern "C" int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Discriminator head: y[r] = h[r,:] . w + b.  One wave per row.
+// Discriminator head: y[r] = h[r,:] . w + b.  One wave per row.  When `delta` is given the same
+// pass also writes the seed of the downward chain, delta[r,j] = rowscale[r] * w[j] * slope[r,j]
+// (what dpc_disc_seed computes), saving a launch per discriminator pass.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void disc_out_kernel(const float* __restrict__ h, int64_t ldh,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       int64_t rows, int d, float* __restrict__ y) {
+                                                       int64_t rows, int d, float* __restrict__ y,
+                                                       const float* __restrict__ rowscale,
+                                                       const float* __restrict__ slope, int64_t lds,
+                                                       float* __restrict__ delta, int64_t ldd) {
   const int lane = threadIdx.x & 63;
   int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= rows) return;
   float acc = 0.f;
-  for (int j = lane; j < d; j += 64) acc += h[r * ldh + j] * w[j];
+  const float rs = delta ? rowscale[r] : 0.f;
+  for (int j = lane; j < d; j += 64) {
+    float wj = w[j];
+    acc += h[r * ldh + j] * wj;
+    if (delta) delta[r * ldd + j] = rs * wj * slope[r * lds + j];
+  }
   acc = dpc_wave_sum(acc);
   if (lane == 0) y[r] = acc + b[0];
 }
 
 extern "C" int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,
-                                float* y, void* stream) {
+                                float* y, const float* rowscale, const float* slope, int64_t lds, float* delta,
+                                int64_t ldd, void* stream) {
   DPC_CHECK_ARG(h && w && b && y && rows > 0 && d > 0, "disc_out_fwd: bad argument");
+  DPC_CHECK_ARG(!delta || (rowscale && slope && lds >= d && ldd >= d), "disc_out_fwd: seed output needs rowscale and slope");
   hipLaunchKernelGGL(disc_out_kernel, dim3((unsigned)dpc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, w, b,
-                     rows, d, y);
+                     rows, d, y, rowscale, slope, lds, delta, ldd);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

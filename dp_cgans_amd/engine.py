@@ -181,7 +181,9 @@ class StepEngine(object):
         self.H = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
         self.S = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
         self.Dl = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
-        self.y = torch.zeros(3 * n, **f32)
+        self.y = torch.zeros(3 * n, **f32)          # discriminator outputs of the latest D update (fake | real | xhat)
+        self.y_g = torch.zeros(n, **f32)            # ... of the latest G update
+        self.y_x = torch.zeros(n, **f32)            # ... of score_real_rows
         rs = torch.empty(3 * n, **f32)
         rs[:n] = 1.0 / self.gn
         rs[n:2 * n] = -1.0 / self.gn
@@ -190,7 +192,9 @@ class StepEngine(object):
         self.rowscale_g = torch.full((n,), -1.0 / self.gn, **f32)
         self.ones_col = torch.ones(2 * n, 1, **f32)
         self.pen_rows = torch.zeros(n, device=d, dtype=torch.float64)
-        self.losses = torch.zeros(4, **f32)          # loss_d, pen, -mean(y_fake), cond loss
+        self._losses = torch.zeros(4, **f32)         # loss_d, pen, -mean(y_fake), cond loss (see `losses`)
+        self._loss_dirty = [False, False]            # D part / G part to be reduced from y, pen_rows, part_loss
+        self._ce_parts = 0
         maxF = max(self.gdim + self.ddim + [self.Dd, 1])
         self.part = torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64)
         # Independent kernels of a step (the real-row sampling chain beside the generator forward, the
@@ -248,6 +252,26 @@ class StepEngine(object):
             _linear_init(w, b, gen)
             self.disc.P('seq.%d.weight' % (3 * i)).copy_(w)
             self.disc.P('seq.%d.bias' % (3 * i)).copy_(b)
+
+    @property
+    def losses(self):
+        """[loss_d, penalty, -mean(y_fake), cond loss]: this rank's additive shares for the latest
+        updates.  The step itself never needs these scalars (the reference reads them once per epoch,
+        dp_cgan.py:735-736), so their final reductions run here, on demand, from the buffers the
+        latest updates left behind (y, pen_rows, cond-loss block partials)."""
+        n = self.n
+        if self._loss_dirty[0]:
+            ops.mean_pair(self.y, n, n / self.gn, -n / self.gn, self._losses[0:1])
+            ops.sum_f64(self.pen_rows, GP_LAMBDA / self.gn, self._losses[1:2])
+            self._loss_dirty[0] = False
+        if self._loss_dirty[1]:
+            ops.mean_pair(self.y_g, n, -n / self.gn, 0.0, self._losses[2:3])
+            if self.has_cond:
+                ops.sum_f64(self.part_loss[:self._ce_parts], 2.0 / (float(self.gB) * self.nd), self._losses[3:4])
+            else:
+                self._losses[3:4].zero_()
+            self._loss_dirty[1] = False
+        return self._losses
 
     def global_losses(self):
         """[loss_d, penalty, -mean(y_fake), cond loss] of the latest updates over the GLOBAL batch
@@ -358,17 +382,24 @@ class StepEngine(object):
                                    site=ops.SITE_GUMBEL + self._so)
             dst.copy_(self.fake)
 
-    def _disc_forward(self, rows, inj, row0=0):
-        d = self.disc
+    def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None):
+        """Discriminator forward over rows [row0, row0+rows) of the stacked input; with ``rowscale`` the
+        head kernel also seeds the backward chain: Dl[M-1] = rowscale * w_last * S[M-1]."""
+        d, M = self.disc, self.M
         rs = slice(row0, row0 + rows)
         x = self.Xd3[rs]
         keeps = inj.get('keep')
-        for i in range(self.M):
+        for i in range(M):
             ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
                      rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
             x = self.H[i][rs]
-        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * self.M)), d.P('seq.%d.bias' % (3 * self.M)), self.y[rs])
+        y = self.y[rs] if y is None else y
+        if rowscale is None:
+            ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), y)
+        else:
+            ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), y, rowscale=rowscale,
+                             slope=self.S[M - 1][rs], delta=self.Dl[M - 1][rs])
 
     def score_real_rows(self, inj=None):
         """Discriminator output on a freshly sampled batch of real rows with their cond vectors
@@ -377,14 +408,13 @@ class StepEngine(object):
         self._so = 0
         self._draw_inputs(inj, need_real=True)
         self._join()
-        self._disc_forward(self.n, inj, row0=self.n)
+        self._disc_forward(self.n, inj, row0=self.n, y=self.y_x)
         ops.state_advance(self.rng)
-        return self.y[self.n:2 * self.n].detach().cpu().view(-1, 1)
+        return self.y_x.detach().cpu().view(-1, 1)
 
     def _disc_chain_down(self, rows, rowscale):
         """D_M = rowscale * w_last * S_M;  D_{i-1} = (D_i W_i) * S_{i-1}."""
-        d, M = self.disc, self.M
-        ops.disc_seed(rowscale, d.P('seq.%d.weight' % (3 * M)), self.S[M - 1][0:rows], self.Dl[M - 1][0:rows])
+        d, M = self.disc, self.M       # (the seed D_M was written by the head kernel of _disc_forward)
         for i in range(M - 1, 0, -1):
             ops.gemm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
                      aux_in=self.S[i - 1][0:rows])
@@ -454,15 +484,14 @@ class StepEngine(object):
         self._join()
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
                         rng=self.rng, site=ops.SITE_ALPHA + self._so)
-        self._disc_forward(3 * n, inj)
-        ops.mean_pair(self.y, n, n / self.gn, -n / self.gn, self.losses[0:1])      # this rank's share of the global means
+        self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
+        self._loss_dirty[0] = True
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
         self._disc_chain_down(3 * n, self.rowscale_d)
         W1 = d.P('seq.0.weight')
         gp_rows = slice(2 * n, 3 * n)
         ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
         ops.gp_norm(self.Xd3[gp_rows], 2.0 * GP_LAMBDA / self.gn, self.pen_rows)    # -> v0 in place
-        ops.sum_f64(self.pen_rows, GP_LAMBDA / self.gn, self.losses[1:2])
         # penalty v-chain first, so that every layer's (delta, input) pair exists before the DP clip
         # factors: v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
         prev = self.Xd3
@@ -472,14 +501,15 @@ class StepEngine(object):
             prev = self.H[i]
         kscale, w_last, w_bias = None, self.rowscale_d, None
         if self.dp_mode == 'dpsgd':
-            # per-example gradient norms (ghost norm over the 3 rows of each pac group), clip factors
-            prev = self.Xd3
+            # per-example gradient norms (ghost norm over the 3 rows of each pac group) of every layer and
+            # the clip factors, one launch
+            layers, prev = [], self.Xd3
             for i in range(M):
-                ops.persample_gram(self.Dl[i], prev, n, self.norm2, with_bias=True, accumulate=i > 0)
+                layers.append((self.Dl[i], prev))
                 prev = self.H[i]
-            ops.persample_gram(self.rowscale_d.view(-1, 1), prev, n, self.norm2, with_bias=True, accumulate=True)
-            ops.clip_factors(self.norm2, self.dp_clip, float(self.gn), self.rowc, roww=self.rowscale_d,
-                             rowc_w=self.rowc_w, norm_out=self.norms)
+            layers.append((self.rowscale_d.view(-1, 1), prev))
+            ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc, roww=self.rowscale_d,
+                                   rowc_w=self.rowc_w, norm_out=self.norms)
             kscale, w_last, w_bias = self.rowc, self.rowc_w, self.rowc[0:2 * n]
         # weight gradients: the first layer's product (K0 wide) on the main stream, everything else beside it
         with self._fork(0) as part:
@@ -535,17 +565,16 @@ class StepEngine(object):
         self._draw_inputs(inj, need_real=False)
         self._gen_forward()
         self._activate(inj)
-        self._disc_forward(n, inj)
-        ops.mean_pair(self.y, n, -n / self.gn, 0.0, self.losses[2:3])
+        self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g)
+        self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
         ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
         if self.has_cond:
             ops.apply_activate_bwd(self.Xd[0:B, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
-            ops.cond_loss(self.fake, self.cond, self.mask, self.col2d, self.col2c, self.nd, self.losses[3:4],
-                          self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
+            self._ce_parts = ops.cond_loss(self.fake, self.cond, self.mask, self.col2d, self.col2c, self.nd, None,
+                                           self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
         else:
             self.dfake.copy_(self.dX)
-            self.losses[3:4].zero_()
         # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations

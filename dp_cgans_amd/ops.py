@@ -122,13 +122,15 @@ def apply_activate_bwd(y, dy, dx, spans, tau=0.2, accumulate=False):
 
 
 def cond_loss(fake, cond, mask, col2d, col2c, nd, loss_out, dfake, partials, accumulate=False, batch_total=0):
+    """loss_out None: only the block partials are written; returns how many (sum them * 2/(B*nd) later)."""
     _chk(mask, torch.int32, 'mask')
     _chk(partials, torch.float64, 'partials')
     B, Dd = fake.shape
+    n_used = ctypes.c_int(0)
     lib().call('dpc_cond_loss', _p(fake), _ld(fake), _p(cond), _ld(cond), _p(mask), _ld(mask), _p(col2d), _p(col2c), B,
                Dd, nd, _p(loss_out), _p(dfake), _ld(dfake) if dfake is not None else 0, int(accumulate), _p(partials),
-               partials.numel(), int(batch_total), _stream())
-    return loss_out
+               partials.numel(), int(batch_total), ctypes.byref(n_used), _stream())
+    return n_used.value
 
 
 def build_bitmaps(table, cat_col, bitmaps):
@@ -228,8 +230,10 @@ def bn_relu_bwd(dy, y, z, mean, invstd, gamma, dbeta, dgamma, count, dz):
                _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), float(count), _p(dz), _ld(dz), _stream())
 
 
-def disc_out_fwd(h, w, b, y):
-    lib().call('dpc_disc_out_fwd', _p(h), _ld(h), _p(w), _p(b), h.shape[0], h.shape[1], _p(y), _stream())
+def disc_out_fwd(h, w, b, y, rowscale=None, slope=None, delta=None):
+    """y = h.w + b; with delta also delta = rowscale[:,None] * w * slope (seed of the backward chain)."""
+    lib().call('dpc_disc_out_fwd', _p(h), _ld(h), _p(w), _p(b), h.shape[0], h.shape[1], _p(y), _p(rowscale), _p(slope),
+               _ld(slope) if slope is not None else 0, _p(delta), _ld(delta) if delta is not None else 0, _stream())
 
 
 def disc_seed(rowscale, w, slope, delta):
@@ -286,3 +290,21 @@ def clip_factors(norm2, clip, gscale, rowc, roww=None, rowc_w=None, norm_out=Non
 def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK, t_add=1):
     lib().call('dpc_hook_noise', _p(seg_add), seg_add.shape[0], _p(fires), _p(t_dev), int(t_add), float(inv_B), _p(rng),
                site, _stream())
+
+
+def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=None, norm_out=None):
+    """layers: [(delta [3n,d], act [3n,K])]; all Gram contractions and the clip factors in one launch."""
+    _chk(norm2, torch.float64, 'norm2')
+    L = len(layers)
+    for dl, ac in layers:
+        _chk(dl, torch.float32, 'delta')
+        _chk(ac, torch.float32, 'act')
+        if dl.shape[0] != 3 * n or ac.shape[0] != 3 * n:
+            raise ValueError('persample_clip_all: delta/act need 3n rows')
+    P = ctypes.c_void_p * L
+    I64 = ctypes.c_int64 * L
+    I32 = ctypes.c_int * L
+    lib().call('dpc_persample_clip_all', L, P(*[dl.data_ptr() for dl, _ in layers]), I64(*[_ld(dl) for dl, _ in layers]),
+               I32(*[dl.shape[1] for dl, _ in layers]), P(*[ac.data_ptr() for _, ac in layers]),
+               I64(*[_ld(ac) for _, ac in layers]), I32(*[ac.shape[1] for _, ac in layers]), n, float(clip),
+               float(gscale), _p(norm2), _p(rowc), _p(roww), _p(rowc_w), _p(norm_out), _stream())

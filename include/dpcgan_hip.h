@@ -84,11 +84,14 @@ int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t
 /* loss_out[0] = 2/(B*nd) sum_b sum_j mask[b,col2d[j]] * BCEWithLogits(fake[b,j], cond[b,col2c[j]]);
  * dfake (nullable) gets d loss / d fake (zero outside discrete columns).  partials: fp64 workspace
  * of n_partials (>= 1, 2048 is enough) elements.  B_total > 0: these B rows are one rank's shard of a
- * global batch of B_total rows (the 1/B of the mean uses B_total, so shares add up over ranks). */
+ * global batch of B_total rows (the 1/B of the mean uses B_total, so shares add up over ranks).
+ * loss_out may be NULL when n_used (host int*) is given: the loss is then
+ * 2/(B_total*nd) * sum(partials[0 : *n_used]), to be taken later with dpc_sum_f64 (the step does not
+ * need the scalar; the reference reads it once per epoch, :735-736). */
 int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, int64_t ldc, const int32_t* mask,
                   int64_t ldm, const int32_t* col2d, const int32_t* col2c, int64_t B, int Dd, int nd,
                   float* loss_out, float* dfake, int64_t lddf, int accumulate, double* partials,
-                  int n_partials, int64_t B_total, void* stream);
+                  int n_partials, int64_t B_total, int* n_used, void* stream);
 
 /* ---- DataSampler (data_sampler.py) ---------------------------------------------------------- */
 /* Tables (replace DataSampler.__init__, data_sampler.py:9-198): bitmaps[C][W] row sets per
@@ -157,9 +160,11 @@ int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, 
                     int64_t ldz, int64_t B, int F, const float* mean, const float* invstd,
                     const float* gamma, const float* dbeta, const float* dgamma, double count,
                     float* dz, int64_t lddz, void* stream);
-/* last Linear(d, 1) of the discriminator (:43) */
+/* last Linear(d, 1) of the discriminator (:43); when delta != NULL the same pass writes the seed
+ * delta[r,j] = rowscale[r] * w[j] * slope[r,j] of the backward / input-gradient chain */
 int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,
-                     float* y, void* stream);
+                     float* y, const float* rowscale, const float* slope, int64_t lds, float* delta,
+                     int64_t ldd, void* stream);
 /* delta[r,j] = rowscale[r] * w[j] * slope[r,j]: seed of the backward / input-gradient chain */
 int dpc_disc_seed(const float* rowscale, const float* w, const float* slope, int64_t lds, int64_t rows,
                   int d, float* delta, int64_t ldd, void* stream);
@@ -194,6 +199,12 @@ int dpc_noise_add_clamp(float* x, int64_t n, float scale, const float* noise_inj
  * matrices (no per-example gradient is formed); with_bias adds ||delta_i + delta_{n+i}||^2. */
 int dpc_persample_gram(const float* delta, int64_t ldd, int d, const float* act, int64_t lda, int K,
                        int64_t n, int with_bias, int accumulate, double* norm2, void* stream);
+/* All layers + clip factors in one launch: delta / act / ldd / lda / d / K are HOST arrays of nlayers
+ * (<= 8) entries; every layer counts its bias.  Outputs as dpc_persample_gram + dpc_clip_factors. */
+int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
+                           const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
+                           float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
+                           float* norm_out, void* stream);
 /* c_i = min(1, clip / (gscale*sqrt(norm2[i]))) -> rowc[p*n+i] (p = 0..2), rowc_w = rowc * roww
  * (nullable), norm_out[i] = gscale*sqrt(norm2[i]) (nullable). */
 int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,
