@@ -158,7 +158,7 @@ struct Stage {
 template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   static_assert(!(KS && A_KC), "kscale needs an m-contiguous A");
-  static_assert(PF == 2, "two register stages");
+  static_assert(PF % 2 == 0, "the LDS buffer parity is taken from the unrolled tile index");
   using SA = Stage<BM, A_KC, KS>;
   using SB = Stage<BN, B_KC>;
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
@@ -206,17 +206,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // (ld >= extent rounded up to 4) for the last 16-byte load to stay inside its row
   const bool fa = g.a_vec && (A_KC ? g.M >= 1 : (m0 + BM <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
   const bool fb = g.b_vec && (B_KC ? g.N >= 1 : (n0 + BN <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
-  // Two register stages per operand, as named objects (an array of stages indexed by the unrolled
-  // tile number made hipcc keep part of the ring in scratch memory).
-  SA sa0, sa1;
-  SB sb0, sb1;
+  // PF register stages per operand (a ring indexed by the unrolled tile number: compile-time indices)
+  SA sa[PF];
+  SB sb[PF];
   const int ntile = (k_end - k_begin + BK - 1) / BK;
   const int nfull = (fa && fb) ? (k_end - k_begin) / BK : 0;
-  const int nmain = nfull & ~1;
+  const int nmain = (nfull / PF) * PF;
   float* const As0 = As;
-  float* const As1 = As + SA::SIZE;
   float* const Bs0 = Bs;
-  float* const Bs1 = Bs + SB::SIZE;
 
   auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
@@ -236,41 +233,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
   };
 
-  // Main pipeline: nmain (even) full K-tiles, strictly branch-free inside (loads past the end are
-  // clamped to the last tile, stores are unconditional), so hipcc keeps a tile of loads in flight
-  // with counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow join.  The
-  // loads of tile t+2 are issued before the MFMAs of tile t and land in LDS one iteration later.
+  // Main pipeline: nmain (a multiple of PF) full K-tiles, strictly branch-free inside (loads past
+  // the end are clamped to the last tile, stores are unconditional), so hipcc keeps PF-1 tiles of
+  // loads in flight with counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow
+  // join.  The loads of tile t+PF are issued before the MFMAs of tile t and land in LDS PF-1
+  // iterations later: with ~1 block per CU nothing else hides the 1-2 us L2/HBM latency.
   if (nmain > 0) {
-    sa0.load_fast(g.A, lda, m0, k_begin, g.M, g.kscale);
-    sb0.load_fast(g.B, ldb, n0, k_begin, g.N);
-    sa1.load_fast(g.A, lda, m0, k_begin + BK, g.M, g.kscale);
-    sb1.load_fast(g.B, ldb, n0, k_begin + BK, g.N);
-    sa0.store(As0);
-    sb0.store(Bs0);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M, g.kscale);
+      sb[j].load_fast(g.B, ldb, n0, k_begin + j * BK, g.N);
+    }
+    sa[0].store(As0);
+    sb[0].store(Bs0);
     __syncthreads();
-    for (int t0 = 0; t0 < nmain; t0 += 2) {
-      int tl = min(t0 + 2, nmain - 1);
-      sa0.load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
-      sb0.load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
-      compute(As0, Bs0);
-      sa1.store(As1);
-      sb1.store(Bs1);
-      __syncthreads();
-      tl = min(t0 + 3, nmain - 1);
-      sa1.load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
-      sb1.load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
-      compute(As1, Bs1);
-      sa0.store(As0);
-      sb0.store(Bs0);
-      __syncthreads();
+    for (int t0 = 0; t0 < nmain; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int cur = u & 1;              // PF is even, so t & 1 == u & 1
+        const int tl = min(t0 + u + PF, nmain - 1);
+        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
+        sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
+        compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
+        sa[(u + 1) % PF].store(As + (cur ^ 1) * SA::SIZE);
+        sb[(u + 1) % PF].store(Bs + (cur ^ 1) * SB::SIZE);
+        __syncthreads();
+      }
     }
   }
-  // Remainder (one odd full tile, a partial last tile, or operands the fast path cannot take).
+  // Remainder (< PF full tiles, a partial last tile, or operands the fast path cannot take).
   for (int t = nmain; t < ntile; ++t) {
-    sa0.load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
-    sb0.load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
-    sa0.store(As0);
-    sb0.store(Bs0);
+    sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
+    sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
+    sa[0].store(As0);
+    sb[0].store(Bs0);
     __syncthreads();
     compute(As0, Bs0);
     __syncthreads();
