@@ -89,11 +89,12 @@ def main():
         'metric': 'DP-CGAN training rows/sec (D+G steps)', 'value': rows / elapsed, 'unit': 'rows/s',
         'n_gpus': dist.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s synthetic table (%d rows, 20 continuous + 30 categorical cols), per-GPU batch %d, '
-                               'pac %d, G/D dims %s, private=True (%s), discriminator_steps %d; BASELINE.json configs[2]'
-                               % (args.table, table.shape[0], args.batch, args.pac, dims,
+        'config': {'workload': '%s synthetic table (%d rows, %d encoded columns), per-GPU batch %d, '
+                               'pac %d, G/D dims %s, private=True (%s), discriminator_steps %d; BASELINE.json configs[%d]'
+                               % (args.table, table.shape[0], table.shape[1], args.batch, args.pac, dims,
                                   'DP-SGD: per-example clip C=1 + Gaussian noise sigma=1' if args.dp_mode == 'dpsgd'
-                                  else 'reference hook-noise + weight clamp', args.d_steps),
+                                  else 'reference hook-noise + weight clamp', args.d_steps,
+                                  {'T1M': 2, 'T10M': 3, 'TWIDE': 4}.get(args.table, 2)),
                    'global_batch': args.batch * dist.world, 'parallelism': 'dp%d' % dist.world,
                    'launch': 'eager' if args.no_graph else 'hipGraph replay (%d segment(s))' % len(gstep.items or []),
                    'data_dim': eng.Dd, 'cond_dim': eng.C, 'n_discrete': eng.nd, 'setup_s': round(setup_s, 2),

@@ -14,20 +14,36 @@
 // ---------------------------------------------------------------------------------------------
 // table construction
 // ---------------------------------------------------------------------------------------------
-// One wave per 64-row word; loops over the discrete columns' categories.  cat_col[a] = column of
-// the encoded matrix that holds category a.
+// One block per 64-row word of the bitmaps.  Lane l of every wave owns category c0 + l of the
+// current chunk of 64 categories and walks its wave's 16 rows, so each row read is one coalesced
+// 256-byte segment when the categories' columns are adjacent (they are: one-hot spans); the four
+// 16-bit partial masks of a category meet in LDS.  cat_col[a] = column of the encoded matrix that
+// holds category a.
 __global__ __launch_bounds__(256) void build_bitmaps_kernel(const float* __restrict__ table, int64_t ld, int64_t N,
                                                             const int32_t* __restrict__ cat_col, int C,
                                                             uint64_t* __restrict__ bitmaps, int64_t W) {
-  int lane = threadIdx.x & 63;
-  int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= W) return;
-  int64_t row = w * 64 + lane;
-  const float* rp = table + row * ld;
-  for (int a = 0; a < C; ++a) {
-    bool bit = (row < N) && (rp[cat_col[a]] != 0.f);
-    unsigned long long m = __ballot(bit);
-    if (lane == 0) bitmaps[(int64_t)a * W + w] = m;
+  __shared__ unsigned short part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t w = blockIdx.x;
+  const int64_t row0 = w * 64 + wave * 16;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int a = c0 + lane;
+    const int col = a < C ? cat_col[a] : 0;
+    unsigned m = 0;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      int64_t row = row0 + rr;
+      bool bit = (a < C) && (row < N) && (table[row * ld + col] != 0.f);
+      m |= (bit ? 1u : 0u) << rr;
+    }
+    part[wave][lane] = (unsigned short)m;
+    __syncthreads();
+    if (wave == 0 && a < C) {
+      uint64_t word = (uint64_t)part[0][lane] | ((uint64_t)part[1][lane] << 16) | ((uint64_t)part[2][lane] << 32) |
+                      ((uint64_t)part[3][lane] << 48);
+      bitmaps[(int64_t)a * W + w] = word;
+    }
+    __syncthreads();
   }
 }
 
@@ -35,45 +51,89 @@ extern "C" int dpc_build_bitmaps(const float* table, int64_t ld, int64_t N, cons
                                  uint64_t* bitmaps, int64_t W, void* stream) {
   DPC_CHECK_ARG(table && cat_col && bitmaps, "build_bitmaps: null pointer");
   DPC_CHECK_ARG(N > 0 && C > 0 && W == (N + 63) / 64, "build_bitmaps: W must be ceil(N/64)");
-  hipLaunchKernelGGL(build_bitmaps_kernel, dim3((unsigned)dpc_cdiv(W, 4)), dim3(256), 0, (hipStream_t)stream, table,
-                     ld, N, cat_col, C, bitmaps, W);
+  hipLaunchKernelGGL(build_bitmaps_kernel, dim3((unsigned)W), dim3(256), 0, (hipStream_t)stream, table, ld, N, cat_col, C,
+                     bitmaps, W);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
 
-// cnt[a][b] (and, when cntblk != NULL, the same count split over S superblocks of Wb = ceil(W/S)
-// bitmap words) for one (a, b) per block.  Wave w of the block takes superblocks w, w+4, ...
+// cnt[a][b] = popcount(bitmaps[a] & bitmaps[b]) (and, when cntblk != NULL, the same count split over
+// S superblocks of Wb = ceil(W/S) bitmap words).  A GEMM-shaped problem over the AND/popcount
+// "semiring": block (ta, tb, sb) owns the 64 x 64 category pairs of tile (ta, tb) for superblock sb,
+// stages 64 + 64 bitmap rows x 32 words through LDS and keeps a 4 x 4 block of counts per thread,
+// so every bitmap word is fetched once per tile row/column instead of once per pair (C = 18 000 on
+// the wide table: 3.2e8 pairs).  Only tiles with tb >= ta are computed; the result is mirrored.
+// Integer atomics into cnt (zeroed here): order-independent.
 __global__ __launch_bounds__(256) void cooccurrence_kernel(const uint64_t* __restrict__ bitmaps, int64_t W, int C,
                                                            int32_t* __restrict__ cnt, int32_t* __restrict__ cntblk,
                                                            int S, int64_t Wb) {
-  __shared__ long long red[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t pair = blockIdx.x;
-  int a = (int)(pair / C), b = (int)(pair - (int64_t)a * C);
-  const uint64_t* pa = bitmaps + (int64_t)a * W;
-  const uint64_t* pb = bitmaps + (int64_t)b * W;
-  long long acc = 0;
-  for (int sb = wave; sb < S; sb += 4) {
-    int64_t w0 = (int64_t)sb * Wb, w1 = min(W, w0 + Wb);
-    int c = 0;
-    for (int64_t w = w0 + lane; w < w1; w += 64) c += __popcll(pa[w] & pb[w]);
-    c = dpc_wave_sum(c);
-    if (lane == 0) {
-      if (cntblk) cntblk[pair * S + sb] = c;
-      acc += c;
+  constexpr int T = 64, WT = 32;
+  __shared__ uint64_t As[T][WT + 1];
+  __shared__ uint64_t Bs[T][WT + 1];
+  const int ta = blockIdx.x, tb = blockIdx.y, sb = blockIdx.z;
+  if (tb < ta) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t w_begin = (int64_t)sb * Wb, w_end = min(W, w_begin + Wb);
+  int acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  for (int64_t w0 = w_begin; w0 < w_end; w0 += WT) {
+#pragma unroll
+    for (int e = threadIdx.x; e < T * WT; e += 256) {
+      int r = e / WT, c = e % WT;
+      int64_t w = w0 + c;
+      int ra = ta * T + r, rb = tb * T + r;
+      As[r][c] = (ra < C && w < w_end) ? bitmaps[(int64_t)ra * W + w] : 0ull;
+      Bs[r][c] = (rb < C && w < w_end) ? bitmaps[(int64_t)rb * W + w] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < WT; ++c) {
+      uint64_t av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[ty * 4 + i][c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[tx * 4 + j][c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(av[i] & bv[j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int a = ta * T + ty * 4 + i, b = tb * T + tx * 4 + j;
+      if (a < C && b < C) {
+        int v = acc[i][j];
+        if (cntblk) {
+          cntblk[((int64_t)a * C + b) * S + sb] = v;
+          cntblk[((int64_t)b * C + a) * S + sb] = v;
+        }
+        if (v) {
+          atomicAdd(&cnt[(int64_t)a * C + b], v);
+          if (ta != tb) atomicAdd(&cnt[(int64_t)b * C + a], v);
+        }
+      }
     }
   }
-  long long tot = dpc_block_sum(acc, red);
-  if (threadIdx.x == 0) cnt[pair] = (int32_t)tot;
 }
 
 extern "C" int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32_t* cnt, int32_t* cntblk, int S,
                                 void* stream) {
   DPC_CHECK_ARG(bitmaps && cnt && W > 0 && C > 0, "cooccurrence: bad argument");
-  DPC_CHECK_ARG((int64_t)C * C < 2147483647LL, "cooccurrence: C*C exceeds the grid limit");
   DPC_CHECK_ARG(S >= 1 && S <= 64 && (cntblk || S == 1), "cooccurrence: 1 <= S <= 64, S > 1 needs cntblk");
-  hipLaunchKernelGGL(cooccurrence_kernel, dim3((unsigned)((int64_t)C * C)), dim3(256), 0, (hipStream_t)stream, bitmaps,
-                     W, C, cnt, cntblk, S, dpc_cdiv(W, S));
+  const int64_t nt = dpc_cdiv(C, 64);
+  DPC_CHECK_ARG(nt <= 65535, "cooccurrence: more than 65535 x 64 categories");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(cnt, 0, (size_t)C * C * sizeof(int32_t), st);
+  if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
+  hipLaunchKernelGGL(cooccurrence_kernel, dim3((unsigned)nt, (unsigned)nt, (unsigned)S), dim3(256), 0, st, bitmaps, W,
+                     C, cnt, cntblk, S, dpc_cdiv(W, S));
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -572,3 +572,41 @@ def test_random_perm_is_a_permutation_and_looks_uniform(ops, B):
         dof = (B - 1) ** 2
         assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof), chi2          # within 6 sigma of the chi-square mean
         assert abs(fixed / T - 1.0) < 0.15                             # a uniform permutation has 1 fixed point on average
+
+
+def test_cooccurrence_tiles_and_bitmaps_on_a_wide_table(ops):
+    """C = 330 categories (6 x 6 tiles of the AND/popcount kernel, mirrored off-diagonal tiles, a
+    ragged last tile), N not a multiple of 64: bitmaps, counts and superblock counts against numpy."""
+    g = np.random.default_rng(5)
+    N, ncol, k = 3001, 55, 3
+    codes = g.integers(k, size=(N, ncol))
+    onehot = np.zeros((N, ncol * k * 2), dtype=np.float32)          # per category v: (is v, is not v)
+    for j in range(ncol):
+        for v in range(k):
+            onehot[:, (j * k + v) * 2] = codes[:, j] == v
+            onehot[:, (j * k + v) * 2 + 1] = codes[:, j] != v
+    C = onehot.shape[1]
+    assert C == 330
+    W = (N + 63) // 64
+    table = torch.from_numpy(onehot).to(dev())
+    cat_col = torch.arange(C, dtype=torch.int32, device=dev())
+    bitmaps = torch.zeros(C, W, dtype=torch.int64, device=dev())
+    ops.build_bitmaps(table, cat_col, bitmaps)
+    bits = np.unpackbits(bitmaps.cpu().numpy().view(np.uint8).reshape(C, W * 8), axis=1, bitorder='little')[:, :N]
+    assert np.array_equal(bits.T.astype(np.float32), onehot)
+    pad = np.unpackbits(bitmaps.cpu().numpy().view(np.uint8).reshape(C, W * 8), axis=1, bitorder='little')[:, N:]
+    assert pad.sum() == 0
+    S = 5
+    cnt = torch.full((C, C), -7, dtype=torch.int32, device=dev())
+    cntblk = torch.full((C, C, S), -7, dtype=torch.int32, device=dev())
+    ops.cooccurrence(bitmaps, cnt, cntblk)
+    ref = (onehot.T.astype(np.int64) @ onehot.astype(np.int64)).astype(np.int32)
+    assert np.array_equal(cnt.cpu().numpy(), ref)
+    Wb = -(-W // S)
+    for sb in range(S):
+        rows = slice(sb * Wb * 64, min(N, (sb + 1) * Wb * 64))
+        part = (onehot[rows].T.astype(np.int64) @ onehot[rows].astype(np.int64)).astype(np.int32)
+        assert np.array_equal(cntblk[:, :, sb].cpu().numpy(), part), sb
+    cnt1 = torch.empty(C, C, dtype=torch.int32, device=dev())
+    ops.cooccurrence(bitmaps, cnt1)                                   # S = 1, no superblock table
+    assert torch.equal(cnt1, cnt)
