@@ -521,3 +521,120 @@ extern "C" int dpc_encode_onehot(const int32_t* codes, int64_t N, int dim, doubl
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// sample() path
+// ---------------------------------------------------------------------------------------------
+// sample_original_condvec (data_sampler.py:348-363): per sample a random table row and a random
+// discrete column; the cond vector gets a single one at cond_st[col] + argmax(table[row, st:st+dim]),
+// st = matrix_st[col].  The reference never fills its matrix offsets (they are all 0):
+// pass matrix_st = NULL for that behaviour, the real span offsets for the intended one.
+// rows_inj / cols_inj (int64, nullable) inject np.random.randint's draws.  One wave per sample.
+__global__ __launch_bounds__(256) void condvec_original_kernel(const float* __restrict__ table, int64_t ld, int64_t N,
+                                                               const int32_t* __restrict__ cond_st,
+                                                               const int32_t* __restrict__ dims,
+                                                               const int32_t* __restrict__ matrix_st, int nd, int C,
+                                                               const int64_t* __restrict__ rows_inj,
+                                                               const int64_t* __restrict__ cols_inj, const uint64_t* rng,
+                                                               uint32_t site, int64_t B, float* __restrict__ cond,
+                                                               int64_t ldc) {
+  const int lane = threadIdx.x & 63;
+  int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int64_t row;
+  int col;
+  if (rows_inj) {
+    row = rows_inj[b];
+    col = (int)cols_inj[b];
+  } else {
+    double u = dpc_u64_to_unit(dpc_draw_u32(rng, site, 4 * (uint64_t)b), dpc_draw_u32(rng, site, 4 * (uint64_t)b + 1));
+    row = min(N - 1, (int64_t)(u * (double)N));
+    float v = dpc_u32_to_unit(dpc_draw_u32(rng, site, 4 * (uint64_t)b + 2));
+    col = min(nd - 1, (int)(v * nd));
+  }
+  const int st = matrix_st ? matrix_st[col] : 0, dim = dims[col];
+  // first maximum of table[row, st : st+dim] (numpy argmax), wave-parallel
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int j = lane; j < dim; j += 64) {
+    float x = table[row * ld + st + j];
+    if (x > best) { best = x; arg = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+  const int hot = cond_st[col] + arg;
+  for (int c = lane; c < C; c += 64) cond[b * ldc + c] = (c == hot) ? 1.f : 0.f;
+}
+
+extern "C" int dpc_condvec_original(const float* table, int64_t ld, int64_t N, const int32_t* cond_st,
+                                    const int32_t* dims, const int32_t* matrix_st, int nd, int C,
+                                    const int64_t* rows_inj, const int64_t* cols_inj, const uint64_t* rng, uint32_t site,
+                                    int64_t B, float* cond, int64_t ldc, void* stream) {
+  DPC_CHECK_ARG(table && cond_st && dims && cond, "condvec_original: null pointer");
+  DPC_CHECK_ARG(N > 0 && nd > 0 && C > 0 && ldc >= C && B >= 0, "condvec_original: bad shape");
+  DPC_CHECK_ARG((rows_inj && cols_inj) || rng, "condvec_original: no random source");
+  if (B == 0) return DPC_OK;
+  hipLaunchKernelGGL(condvec_original_kernel, dim3((unsigned)dpc_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, table,
+                     ld, N, cond_st, dims, matrix_st, nd, C, rows_inj, cols_inj, rng, site, B, cond, ldc);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// DataTransformer.inverse_transform (data_transformer.py:152-213) for generated rows: per output
+// column j, desc[j] = (kind, data offset, width, parameter offset).  kind 0 (continuous): value =
+// clip(data[off], -1, 1), component = valid_idx[argmax(data[off+1 : off+width])],
+// out = value * 4 * std[component] + mean[component]  (fp64; params = [mean(Kc) | std(Kc) | valid_idx(nv)]
+// at the parameter offset, Kc = desc width of the mixture = params_k).  kind 1 (discrete):
+// out = argmax(data[off : off+width]) as a category index.  One thread per (row, column).
+__global__ __launch_bounds__(256) void inverse_transform_kernel(const float* __restrict__ data, int64_t ld, int64_t n,
+                                                                const int32_t* __restrict__ desc, int ncol,
+                                                                const double* __restrict__ params, int Kc,
+                                                                double* __restrict__ out, int64_t ldo) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * ncol) return;
+  int64_t r = idx / ncol;
+  int j = (int)(idx - r * ncol);
+  const int kind = desc[4 * j], off = desc[4 * j + 1], width = desc[4 * j + 2], po = desc[4 * j + 3];
+  const float* d = data + r * ld + off;
+  if (kind == 0) {
+    float v = fminf(fmaxf(d[0], -1.f), 1.f);
+    int arg = 0;
+    float best = d[1];
+    for (int t = 1; t < width - 1; ++t) {
+      float x = d[1 + t];
+      if (x > best) { best = x; arg = t; }
+    }
+    const double* mean = params + po;
+    const double* sd = params + po + Kc;
+    int comp = (int)params[po + 2 * Kc + arg];
+    // numpy: float32 value * 4 (float32), then * std + mean in float64 with two roundings: keep
+    // hipcc from contracting them into one fma (HIP's __dmul_rn / __dadd_rn are plain operators)
+    {
+#pragma clang fp contract(off)
+      double t = (double)(v * 4.f) * sd[comp];
+      out[r * ldo + j] = t + mean[comp];
+    }
+  } else {
+    int arg = 0;
+    float best = d[0];
+    for (int t = 1; t < width; ++t) {
+      float x = d[t];
+      if (x > best) { best = x; arg = t; }
+    }
+    out[r * ldo + j] = (double)arg;
+  }
+}
+
+extern "C" int dpc_inverse_transform(const float* data, int64_t ld, int64_t n, const int32_t* desc, int ncol,
+                                     const double* params, int Kc, double* out, int64_t ldo, void* stream) {
+  DPC_CHECK_ARG(data && desc && out && ncol > 0 && n >= 0 && ldo >= ncol && Kc >= 1, "inverse_transform: bad argument");
+  if (n == 0) return DPC_OK;
+  hipLaunchKernelGGL(inverse_transform_kernel, dim3((unsigned)dpc_cdiv(n * ncol, 256)), dim3(256), 0, (hipStream_t)stream,
+                     data, ld, n, desc, ncol, params, Kc, out, ldo);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}

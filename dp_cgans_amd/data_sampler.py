@@ -45,6 +45,7 @@ class DataSampler(object):
         self.cat_col = torch.from_numpy(cat_col).to(self.dev)
         self.cond_st = torch.tensor([c[1] for c in cols], dtype=torch.int32, device=self.dev)
         self.dims = torch.tensor([c[2] for c in cols], dtype=torch.int32, device=self.dev)
+        self._matrix_st_dev = torch.tensor([c[0] for c in cols], dtype=torch.int32, device=self.dev)
         self.W = (self.N + 63) // 64
         self.bitmaps = torch.zeros(C, self.W, dtype=torch.int64, device=self.dev)
         self.cnt = torch.zeros(C, C, dtype=torch.int32, device=self.dev)
@@ -123,26 +124,25 @@ class DataSampler(object):
         ops.state_advance(self.rng)
         return rid.cpu().numpy(), out.cpu().numpy()
 
-    def sample_original_condvec(self, batch):
-        """Cond vector for generation (data_sampler.py:348-363).  The reference reads the one-hot of
-        column 0's span for every discrete column (its _discrete_column_matrix_st is never filled,
-        SURVEY Q9); that quirk is kept: pick = argmax(data[row, 0:n_cat(col)])."""
+    def sample_original_condvec_device(self, batch, rows=None, cols=None):
+        """Cond vector for generation (data_sampler.py:348-363) as a device tensor [batch, C].  The
+        reference reads column 0's span for every discrete column (its _discrete_column_matrix_st is
+        never filled); reference_quirks=True keeps that."""
         if self._n_discrete_columns == 0:
             return None
-        g = torch.Generator().manual_seed(int(self.rng[1].item()) + 12345)
+        d = self.dev
+        cond = torch.empty(batch, self._n_categories, device=d)
+        mst = None if self.reference_quirks else self._matrix_st_dev
+        rj = torch.as_tensor(np.asarray(rows, dtype=np.int64)).to(d) if rows is not None else None
+        cj = torch.as_tensor(np.asarray(cols, dtype=np.int64)).to(d) if cols is not None else None
+        ops.condvec_original(self.table, self.cond_st, self.dims, mst, cond, rows_inj=rj, cols_inj=cj, rng=self.rng)
         ops.state_advance(self.rng)
-        rows = torch.randint(0, self.N, (batch,), generator=g)
-        cols = torch.randint(0, self._n_discrete_columns, (batch,), generator=g)
-        cond = np.zeros((batch, self._n_categories), dtype='float32')
-        tab = self.table[rows.to(self.dev)].cpu().numpy()
-        dims = self._categories_each_column
-        cst = self.cond_st.cpu().numpy()
-        for i in range(batch):
-            c = int(cols[i])
-            st = 0 if self.reference_quirks else int(self._matrix_st[c])
-            pick = int(np.argmax(tab[i, st:st + dims[c]]))
-            cond[i, pick + cst[c]] = 1
         return cond
+
+    def sample_original_condvec(self, batch, rows=None, cols=None):
+        """Reference-shaped host API: numpy float32 [batch, C] (or None without discrete columns)."""
+        cond = self.sample_original_condvec_device(batch, rows, cols)
+        return None if cond is None else cond.cpu().numpy()
 
     def generate_cond_from_condition_column_info(self, condition_info, batch):
         """data_sampler.py:401-406 (the reference adds value_id to a matrix offset that is always 0, Q9)."""

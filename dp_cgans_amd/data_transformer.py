@@ -199,6 +199,41 @@ class DataTransformer(object):
         recovered = pd.DataFrame(dict(zip(names, cols)), columns=names).astype(self._column_raw_dtypes)
         return recovered if self.dataframe else recovered.values
 
+    def _decode_tables(self):
+        """(desc int32 [ncol,4], params fp64, Kc) for dpc_inverse_transform."""
+        Kc = self._max_clusters
+        desc, params, st = [], [], 0
+        for info in self._column_transform_info_list:
+            if info.column_type == 'continuous':
+                gt = info.transform
+                desc.append((0, st, info.output_dimensions, len(params)))
+                params += list(gt.means) + list(gt.stds) + [float(v) for v in gt.valid_idx]
+                params += [0.0] * (Kc - len(gt.valid_idx))
+            else:
+                desc.append((1, st, info.output_dimensions, 0))
+            st += info.output_dimensions
+        return (np.array(desc, dtype=np.int32).reshape(-1, 4), np.array(params if params else [0.0], dtype=np.float64), Kc)
+
+    def inverse_transform_device(self, data):
+        """``inverse_transform`` (sigmas=None) of a device fp32 matrix on the device: one kernel decodes
+        every column (argmax + de-normalise), one [n, n_columns] fp64 matrix comes back to the host,
+        where category indices become labels."""
+        desc, params, Kc = self._decode_tables()
+        dev = data.device
+        out = torch.empty(data.shape[0], desc.shape[0], dtype=torch.float64, device=dev)
+        ops.inverse_transform(data, torch.from_numpy(desc).to(dev), torch.from_numpy(params).to(dev), Kc, out)
+        host = out.cpu().numpy()
+        cols, names = [], []
+        for j, info in enumerate(self._column_transform_info_list):
+            if info.column_type == 'continuous':
+                cols.append(host[:, j])
+            else:
+                dummies = info.transform.dummies
+                cols.append(pd.Series([dummies[int(i)] for i in host[:, j]]).to_numpy())
+            names.append(info.column_name)
+        recovered = pd.DataFrame(dict(zip(names, cols)), columns=names).astype(self._column_raw_dtypes)
+        return recovered if self.dataframe else recovered.values
+
     def convert_column_name_value_to_id(self, column_name, value):
         discrete_counter = 0
         column_id = 0

@@ -308,3 +308,22 @@ def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=N
                I32(*[dl.shape[1] for dl, _ in layers]), P(*[ac.data_ptr() for _, ac in layers]),
                I64(*[_ld(ac) for _, ac in layers]), I32(*[ac.shape[1] for _, ac in layers]), n, float(clip),
                float(gscale), _p(norm2), _p(rowc), _p(roww), _p(rowc_w), _p(norm_out), _stream())
+
+
+def condvec_original(table, cond_st, dims, matrix_st, cond, rows_inj=None, cols_inj=None, rng=None, site=SITE_CONDVEC):
+    _chk(rows_inj, torch.int64, 'rows_inj')
+    _chk(cols_inj, torch.int64, 'cols_inj')
+    _chk(matrix_st, torch.int32, 'matrix_st')
+    lib().call('dpc_condvec_original', _p(table), _ld(table), table.shape[0], _p(cond_st), _p(dims), _p(matrix_st),
+               dims.shape[0], cond.shape[1], _p(rows_inj), _p(cols_inj), _p(rng), site, cond.shape[0], _p(cond), _ld(cond),
+               _stream())
+    return cond
+
+
+def inverse_transform(data, desc, params, Kc, out):
+    _chk(desc, torch.int32, 'desc')
+    _chk(params, torch.float64, 'params')
+    _chk(out, torch.float64, 'out')
+    lib().call('dpc_inverse_transform', _p(data), _ld(data), data.shape[0], _p(desc), desc.shape[0], _p(params), int(Kc),
+               _p(out), _ld(out), _stream())
+    return out

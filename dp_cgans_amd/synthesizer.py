@@ -245,13 +245,12 @@ class DPCGANSynthesizer(object):
         data = []
         for _ in range(steps):
             if global_condition_vec is not None:
-                condvec = global_condition_vec
+                cond = torch.as_tensor(global_condition_vec).to(eng.dev)
             else:
-                condvec = self._data_sampler.sample_original_condvec(eng.B)
-            cond = None if condvec is None else torch.as_tensor(condvec).to(eng.dev)
-            data.append(eng.sample_forward(cond).cpu().numpy())
-        data = np.concatenate(data, axis=0)[:n]
-        return self._transformer.inverse_transform(data)
+                cond = self._data_sampler.sample_original_condvec_device(eng.B)
+            data.append(eng.sample_forward(cond))
+        data = torch.cat(data, dim=0)[:n]
+        return self._transformer.inverse_transform_device(data)
 
     def set_device(self, device):
         self._device = torch.device(device)

@@ -141,6 +141,21 @@ int dpc_encode_continuous(const double* x, int64_t x_stride, int64_t N, const do
 int dpc_encode_onehot(const int32_t* codes, int64_t N, int dim, double* out64, float* out32,
                       int64_t ldo, int col_off, void* stream);
 
+/* ---- sample() path (DPCGANSynthesizer.sample, dp_cgan.py:838-888) ----------------------------- */
+/* sample_original_condvec (data_sampler.py:348-363): one one per row of cond at cond_st[col] +
+ * argmax(table[row, st:st+dims[col]]), st = matrix_st ? matrix_st[col] : 0 (the reference's offsets
+ * are never filled, i.e. all 0).  rows_inj / cols_inj: np.random.randint's draws (int64, nullable). */
+int dpc_condvec_original(const float* table, int64_t ld, int64_t N, const int32_t* cond_st,
+                         const int32_t* dims, const int32_t* matrix_st, int nd, int C,
+                         const int64_t* rows_inj, const int64_t* cols_inj, const uint64_t* rng,
+                         uint32_t site, int64_t B, float* cond, int64_t ldc, void* stream);
+/* DataTransformer.inverse_transform (data_transformer.py:152-213) of generated rows.  desc int32
+ * [ncol][4] = (kind 0 continuous / 1 discrete, data offset, width, parameter offset); params fp64:
+ * per continuous column [mean(Kc) | std(Kc) | valid component indices (as doubles)].  out fp64
+ * [n][ncol]: de-normalised value, or the category index of a discrete column. */
+int dpc_inverse_transform(const float* data, int64_t ld, int64_t n, const int32_t* desc, int ncol,
+                          const double* params, int Kc, double* out, int64_t ldo, void* stream);
+
 /* ---- generator / discriminator glue (dp_cgan.py:31-100) ------------------------------------- */
 /* Column reductions, two steps so that a data-parallel run can all-reduce `part` in between.
  * mode 0: sum x, sum x^2 (BatchNorm1d batch statistics, :76); 1: sum w[r]*x (bias gradients);

@@ -181,3 +181,38 @@ def test_numeric_only_table_without_discrete_columns(in_tmp):
     s.fit(df)
     out = s.sample(40)
     assert out.shape == (40, 2) and np.isfinite(out.to_numpy()).all()
+
+
+def test_sample_path_kernels_match_the_host_restatement():
+    """sample_original_condvec (data_sampler.py:348-363, with and without the zero-offset quirk) and
+    inverse_transform (data_transformer.py:152-213) on the device against numpy, bit for bit."""
+    from dp_cgans_amd.data_sampler import DataSampler
+    z = load('adult_encode.npz')
+    tr, table = golden_transformer(z, 'cuda:0')
+    enc, span = z['encoded'], z['span_info']
+    g = np.random.default_rng(3)
+    B = 500
+    rows, cols = g.integers(0, enc.shape[0], B), g.integers(0, 19, B)
+    for quirks in (True, False):
+        ds = DataSampler(enc, span, device='cuda:0', reference_quirks=quirks)
+        cond = ds.sample_original_condvec(B, rows=rows, cols=cols)
+        want = np.zeros((B, ds._n_categories), dtype=np.float32)
+        dims, cst, mst = ds._categories_each_column, ds.cond_st.cpu().numpy(), ds._matrix_st
+        for i in range(B):
+            st = 0 if quirks else int(mst[cols[i]])
+            pick = int(np.argmax(enc[rows[i], st:st + dims[cols[i]]]))
+            want[i, pick + cst[cols[i]]] = 1
+        assert cond.dtype == np.float32 and np.array_equal(cond, want), quirks
+        free = ds.sample_original_condvec(B)
+        assert (free.sum(1) == 1).all() and set(np.unique(free)) == {0.0, 1.0}
+    # decode: random "generator outputs" (tanh range values, soft one-hots with ties)
+    Dd = enc.shape[1]
+    fake = g.random((1000, Dd)).astype(np.float32)
+    fake[:, 0] = g.uniform(-1.2, 1.2, 1000)               # beyond the clip range too
+    fake[::7, 1:3] = 0.5                                   # ties: first maximum wins
+    host = tr.inverse_transform(fake)
+    devd = tr.inverse_transform_device(torch.from_numpy(fake).to('cuda:0'))
+    assert list(host.columns) == list(devd.columns)
+    for c in host.columns:
+        assert host[c].dtype == devd[c].dtype, c
+        assert np.array_equal(host[c].to_numpy(), devd[c].to_numpy()), c
