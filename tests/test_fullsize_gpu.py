@@ -1,0 +1,112 @@
+"""BASELINE.json's full size (configs[2]: 1M-row synthetic table, batch 8192, pac 8, dims (256,256),
+private=True) checked through size-independent properties - the oracle cannot run at this size in
+seconds, so what is asserted here is what must hold for ANY correct implementation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def t1m():
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.synthetic import build_encoded_table
+    table, span = build_encoded_table('T1M', DEV)
+    sampler = DataSampler(table, span, device=DEV, seed=17)
+    return table, span, sampler
+
+
+def test_encode_round_trip_and_one_hot_structure(t1m):
+    table, span, _ = t1m
+    assert table.shape == (1000000, 335)
+    st = 0
+    for dim, sm, ncol in span.tolist():
+        blk = table[:, st:st + dim]
+        if sm:            # every softmax span of the encoded table is an exact one-hot
+            assert torch.equal(blk.sum(1), torch.ones(table.shape[0], device=DEV))
+            assert ((blk == 0) | (blk == 1)).all()
+        else:             # values are clipped to +-0.99 (data_transformer.py:122)
+            assert float(blk.abs().max()) <= float(np.float32(0.99))
+        st += dim
+    # continuous column 0 has one mixture component (mu 0, sigma 1): value = clip(x / 4)
+    x = table[:, 0].double() * 4.0
+    inside = table[:, 0].abs() < 0.98
+    assert abs(float(x[inside].mean())) < 0.01 and abs(float(x[inside].std()) - 1.0) < 0.01
+
+
+def test_sampler_tables_are_consistent(t1m):
+    table, span, s = t1m
+    cnt = s.cnt.cpu().numpy().astype(np.int64)
+    C = cnt.shape[0]
+    diag = np.diag(cnt)
+    onehot_sums = table[:, s.cat_col.long()].sum(0).cpu().numpy().astype(np.int64)
+    assert np.array_equal(diag, onehot_sums)                    # cnt[a][a] = rows with category a
+    assert np.array_equal(cnt, cnt.T)
+    cst, dims = s.cond_st.cpu().numpy(), s.dims.cpu().numpy()
+    for j in range(len(dims)):                                   # marginalising a column gives the other's count
+        assert np.array_equal(cnt[:, cst[j]:cst[j] + dims[j]].sum(1), diag), j
+    assert torch.equal(s.cntblk.sum(2, dtype=torch.int64), s.cnt.long())
+    assert int(s.cntblk.shape[2]) == 64
+
+
+def test_conditional_sampling_properties(t1m):
+    table, span, s = t1m
+    from dp_cgans_amd import ops
+    B = 8192
+    cond, mask, pid, vid = s.sample_condvec_pair(B)
+    assert (cond.sum(1) == 2).all() and (mask.sum(1) == 2).all()
+    sel, gcount = s._last_sel[0], s._last_sel[1]
+    cnt = s.cnt
+    assert torch.equal(gcount, cnt[sel[:, 0].long(), sel[:, 1].long()].long())
+    perm = torch.randperm(B).numpy()
+    rid, rows = s.rows_for(perm)
+    assert rid.min() >= 0 and rid.max() < table.shape[0]
+    cc = s.cat_col.cpu().numpy()
+    selp = sel.cpu().numpy()[perm]
+    assert (rows[np.arange(B), cc[selp[:, 0]]] == 1).all() and (rows[np.arange(B), cc[selp[:, 1]]] == 1).all()
+    assert np.array_equal(rows, table[torch.from_numpy(rid).to(DEV)].cpu().numpy())
+    # the k-th pick is monotone in k: ranks 0 .. g-1 of one group give strictly increasing row ids
+    g = int(gcount[0])
+    ks = torch.arange(min(g, 4096), device=DEV)
+    out = torch.empty(len(ks), dtype=torch.int64, device=DEV)
+    ops.row_select(s.bitmaps, sel[0:1].repeat(len(ks), 1).contiguous(), gcount[0:1].repeat(len(ks)).contiguous(), out,
+                   k_inj=ks, cntblk=s.cntblk)
+    assert (out[1:] > out[:-1]).all()
+
+
+@pytest.mark.parametrize('mode', ['dpsgd', 'reference'])
+def test_training_steps_at_full_size(t1m, mode):
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    table, span, s = t1m
+    clip = 1e-3 if mode == 'dpsgd' else 1.0
+    eng = StepEngine(span, 128, (256, 256), (256, 256), 8192, 8, DEV, private=True, dp_mode=mode, dp_sigma=0.0 if mode == 'dpsgd' else 1.0,
+                     dp_clip=clip, seed=0)
+    eng.sampler = s
+    p0 = eng.disc.p.clone()
+    gs = GraphStep(eng, 1)
+    for _ in range(4):
+        gs.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.disc.p).all() and torch.isfinite(eng.gen.p).all()
+    assert torch.isfinite(eng.losses).all()
+    assert not torch.equal(p0, eng.disc.p)
+    assert int(eng.disc.t) == 4 and int(eng.gen.t) == 4 and eng.rng.cpu().tolist()[1] == 4
+    fake = eng.Xd[0:8192, :335]
+    st = 0
+    for dim, sm, _ in span.tolist():          # activated generator output: tanh range / softmax simplex
+        blk = fake[:, st:st + dim]
+        if sm:
+            assert torch.allclose(blk.sum(1), torch.ones(8192, device=DEV), atol=1e-5) and float(blk.min()) >= 0
+        else:
+            assert float(blk.abs().max()) <= 1.0
+        st += dim
+    if mode == 'dpsgd':
+        # every example is clipped (bound far below the norms): the summed gradient of n examples of
+        # norm <= C, divided by n, has norm <= C; and the clip factors are in (0, 1]
+        assert float(eng.rowc.max()) <= 1.0 and float(eng.rowc.min()) > 0
+        assert float(eng.norms.min()) > clip
+        assert float(eng.disc.g.double().norm()) <= clip * (1 + 1e-4)
+    else:
+        assert float(eng.disc.p.abs().max()) <= 0.01 + 1e-9           # weight clamp
