@@ -209,18 +209,31 @@ __global__ __launch_bounds__(256) void noise_add_clamp_kernel(float* x, int64_t 
   float4* x4 = reinterpret_cast<float4*>(x);
   const float4* j4 = reinterpret_cast<const float4*>(inj);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // one quad per iteration: with 32 waves per CU resident the loads of other waves cover this one's
-  // Philox + Box-Muller (two quads in flight per thread measured 7 % slower: VALU-bound, not latency-bound)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 v = x4[i];
-    float z[4];
-    if (inj) {
-      float4 q = j4[i];
-      z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
-    } else {
-      dpc_normal4(rng, site, (uint64_t)i, z);       // normals 4i .. 4i+3 (same map as dpc_draw_normal)
+  // Four 16-byte loads in flight per thread (quads t, t+256, t+512, t+768 of the block's 1024-quad
+  // chunk: every wave instruction is one coalesced KiB), issued before any of the Philox / Box-Muller
+  // work; one load per thread left the kernel bound by bytes in flight (32 KiB per CU), not by HBM
+  // or by the VALU.  Noise and stores then go quad by quad to keep the register count at 8 waves/SIMD.
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n4; base += (int64_t)gridDim.x * 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t i = base + j * 256 + threadIdx.x;
+      if (i < n4) v[j] = x4[i];
     }
-    x4[i] = noise_clamp4(v, z, scale, clamp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t i = base + j * 256 + threadIdx.x;
+      if (i < n4) {
+        float z[4];
+        if (inj) {
+          float4 q = j4[i];
+          z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+        } else {
+          dpc_normal4(rng, site, (uint64_t)i, z);       // normals 4i .. 4i+3 (same map as dpc_draw_normal)
+        }
+        x4[i] = noise_clamp4(v[j], z, scale, clamp);
+      }
+    }
   }
   // tail (n % 4 elements)
   for (int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
@@ -237,7 +250,7 @@ extern "C" int dpc_noise_add_clamp(float* x, int64_t n, float scale, const float
   DPC_CHECK_ARG(noise_inj || rng, "noise_add_clamp: no noise source");
   DPC_CHECK_ARG(((uintptr_t)x & 15) == 0 && (!noise_inj || ((uintptr_t)noise_inj & 15) == 0), "noise_add_clamp: buffers must be 16-byte aligned");
   if (n <= 0) return n == 0 ? DPC_OK : DPC_EINVAL;
-  hipLaunchKernelGGL(noise_add_clamp_kernel, dim3(dpc_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(noise_add_clamp_kernel, dim3(dpc_grid((n + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream,
                      x, n, scale, noise_inj, rng, site, clamp);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
