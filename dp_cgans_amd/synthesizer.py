@@ -183,6 +183,9 @@ class DPCGANSynthesizer(object):
         if loss_file:
             loss_file.write('Epoch,Generator_Loss,Discriminator_Loss,Timestamp\n')
         self.epsilon = float('nan')
+        import time
+        torch.cuda.synchronize(self._device)
+        t_loop = time.perf_counter()
         for i in range(epochs):
             for _ in range(steps_per_epoch):
                 if gstep is not None:
@@ -199,6 +202,10 @@ class DPCGANSynthesizer(object):
                 loss_file.flush()
             if self.private:
                 self.epsilon = self._privacy_report(i, steps_per_epoch, n_rows)
+        torch.cuda.synchronize(self._device)
+        # wall time of the step loop (the metric's denominator: rows/s = batch x steps / this), kept for reports
+        self.step_loop_seconds = time.perf_counter() - t_loop
+        self.steps_done = epochs * steps_per_epoch
         if loss_file:
             loss_file.close()
         self.loss_values = pd.DataFrame(rows, columns=['Epoch', 'Generator Loss', 'Distriminator Loss'])
@@ -218,7 +225,11 @@ class DPCGANSynthesizer(object):
             q = self._batch_size / n_rows
             steps = epoch * steps_per_epoch
             sigma = 1
-        rdp = compute_rdp(q=min(q, 1.0), noise_multiplier=sigma, steps=steps, orders=orders)
+        # compute_rdp is linear in `steps`: the 99 per-composition values are computed once per fit
+        key = (min(q, 1.0), sigma)
+        if getattr(self, '_rdp_cache', (None, None))[0] != key:
+            self._rdp_cache = (key, compute_rdp(q=key[0], noise_multiplier=sigma, steps=1, orders=orders))
+        rdp = self._rdp_cache[1] * steps
         epsilon, _, opt_order = get_privacy_spent(orders, rdp, target_delta=delta)
         if self._verbose:
             print('differential privacy with eps = {:.3g} and delta = {}.'.format(epsilon, delta))
