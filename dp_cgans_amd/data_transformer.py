@@ -1,8 +1,8 @@
 """DataTransformer: mode-specific normalisation of continuous columns and one-hot encoding of
 discrete ones.  Same interface as the reference class
-(/root/reference/src/dp_cgans/synthesizers/data_transformer.py:16-239); ``fit`` runs sklearn's
-BayesianGaussianMixture on the host with the reference's hyper-parameters (:38-47; a later scope row,
-SURVEY 8f-3), ``transform`` runs on the device (csrc/sampler.hip: encode_continuous_kernel,
+(/root/reference/src/dp_cgans/synthesizers/data_transformer.py:16-239); ``fit`` runs the reference's
+variational Bayesian mixture (:38-47, scikit-learn's algorithm) for all continuous columns at once on
+the device (gmm_fit.py, csrc/gmm.hip), ``transform`` runs on the device (csrc/sampler.hip: encode_continuous_kernel,
 encode_onehot_kernel) and ``inverse_transform`` restates :152-213 in numpy.
 """
 from collections import namedtuple
@@ -86,20 +86,27 @@ class DataTransformer(object):
         self._device = torch.device(device)
         self._seed = seed
 
-    def _fit_continuous(self, column_name, raw_column_data):
-        """Train Bayesian GMM for continuous column (data_transformer.py:36-57)."""
-        from sklearn.mixture import BayesianGaussianMixture
-        gm = BayesianGaussianMixture(
-            n_components=self._max_clusters, covariance_type='full',
-            weight_concentration_prior_type='dirichlet_process', weight_concentration_prior=1e-3,
-            n_init=5, max_iter=2000, warm_start=True, init_params='random')
-        gm.fit(np.asarray(raw_column_data, dtype=np.float64).reshape(-1, 1))
-        valid = gm.weights_ > self._weight_threshold
+    def _mixture(self):
+        from .gmm_fit import DeviceBayesianGMM
+        return DeviceBayesianGMM(n_components=self._max_clusters, weight_concentration_prior=1e-3, n_init=5,
+                                 max_iter=2000, device=self._device, seed=self._seed)
+
+    def _continuous_info(self, column_name, fit):
+        valid = fit.weights > self._weight_threshold
+        table = GaussianMixtureTable(fit.means, fit.covariances, fit.precisions_cholesky, fit.weight_concentration,
+                                     fit.mean_precision, fit.degrees_of_freedom, valid)
+        table.lower_bound, table.n_iter, table.converged, table.weights = fit.lower_bound, fit.n_iter, fit.converged, fit.weights
         num_components = int(valid.sum())
         return ColumnTransformInfo(
-            column_name=column_name, column_type='continuous', transform=GaussianMixtureTable.from_sklearn(gm, valid),
+            column_name=column_name, column_type='continuous', transform=table,
             transform_aux=valid, output_info=[SpanInfo(1, 'tanh'), SpanInfo(num_components, 'softmax')],
             output_dimensions=1 + num_components)
+
+    def _fit_continuous(self, column_name, raw_column_data):
+        """Train Bayesian GMM for continuous column (data_transformer.py:36-57): the reference's
+        BayesianGaussianMixture hyper-parameters (:38-47), fitted on the device (gmm_fit.py)."""
+        x = np.asarray(raw_column_data, dtype=np.float64).reshape(1, -1)
+        return self._continuous_info(column_name, self._mixture().fit_columns(x)[0])
 
     def _fit_discrete(self, column_name, raw_column_data):
         """Fit one hot encoder for discrete column (data_transformer.py:59-71)."""
@@ -120,11 +127,17 @@ class DataTransformer(object):
             raw_data = pd.DataFrame(raw_data, columns=[str(i) for i in range(raw_data.shape[1])])
         self._column_raw_dtypes = raw_data.infer_objects().dtypes
         self._column_transform_info_list = []
+        # every continuous column and every initialisation in one batch of device fits
+        cont = [c for c in raw_data.columns if c not in discrete_columns]
+        fits = {}
+        if cont:
+            x = np.stack([np.asarray(raw_data[c].values, dtype=np.float64) for c in cont])
+            fits = dict(zip(cont, self._mixture().fit_columns(x)))
         for column_name in raw_data.columns:
             if column_name in discrete_columns:
                 info = self._fit_discrete(column_name, raw_data[column_name])
             else:
-                info = self._fit_continuous(column_name, raw_data[column_name].values)
+                info = self._continuous_info(column_name, fits[column_name])
             self.output_info_list.append(info.output_info)
             self.output_dimensions += info.output_dimensions
             self._column_transform_info_list.append(info)

@@ -200,6 +200,27 @@ def encode_continuous(x, tab, valid_idx, out64=None, out32=None, col_off=0, u_in
                _stream())
 
 
+def gmm_estep(x, fit_col, params, prior, info, part, init, resp_inj=None, rng=None, site=0x4000):
+    """x fp64 [ncol, N] (column-major table), params [F, 8, K], prior [F, 2], info [F, 4], part [F, R, 3K+1]."""
+    for t, n in ((x, 'x'), (params, 'params'), (prior, 'prior'), (info, 'info'), (part, 'part'), (resp_inj, 'resp_inj')):
+        _chk(t, torch.float64, n)
+    _chk(fit_col, torch.int32, 'fit_col')
+    F, _, K = params.shape
+    assert x.stride(1) == 1 and part.shape[0] == F and part.shape[2] == 3 * K + 1 and part.is_contiguous()
+    assert params.is_contiguous() and prior.shape == (F, 2) and info.shape == (F, 4) and fit_col.shape[0] == F
+    if resp_inj is not None:
+        assert resp_inj.shape == (F, x.shape[1], K) and resp_inj.is_contiguous()
+    lib().call('dpc_gmm_estep', _p(x), x.stride(0), x.shape[1], _p(fit_col), F, _p(params), K, _p(prior), _p(info),
+               1 if init else 0, _p(resp_inj), _p(rng), site, _p(part), part.shape[1], _stream())
+
+
+def gmm_mstep(part, prior, params, info, init, weight_concentration_prior=1e-3, mean_precision_prior=1.0,
+              dof_prior=1.0, reg_covar=1e-6, tol=1e-3, max_iter=2000):
+    F, _, K = params.shape
+    lib().call('dpc_gmm_mstep', _p(part), part.shape[1], F, K, _p(prior), _p(params), _p(info), 1 if init else 0,
+               weight_concentration_prior, mean_precision_prior, dof_prior, reg_covar, tol, max_iter, _stream())
+
+
 def encode_onehot(codes, dim, out64=None, out32=None, col_off=0):
     _chk(codes, torch.int32, 'codes')
     out = out64 if out64 is not None else out32

@@ -141,6 +141,31 @@ int dpc_encode_continuous(const double* x, int64_t x_stride, int64_t N, const do
 int dpc_encode_onehot(const int32_t* codes, int64_t N, int dim, double* out64, float* out32,
                       int64_t ldo, int col_off, void* stream);
 
+/* ---- DataTransformer._fit_continuous (data_transformer.py:36-57) ---------------------------- */
+/* sklearn's BayesianGaussianMixture (one feature, 'full' covariance, dirichlet_process weights,
+ * init_params='random') for F independent fits side by side; fit f reads column fit_col[f] of the
+ * column-major fp64 table x[col*col_stride + row].  One iteration = dpc_gmm_estep + dpc_gmm_mstep.
+ *   params fp64 [F][8][K]: mu, precision_cholesky, A (see dpc_encode_continuous), covariance,
+ *                          stick a, stick b, mean_precision, degrees_of_freedom;
+ *   prior  fp64 [F][2]:    mean_prior (column mean), covariance_prior (column variance, ddof 1);
+ *   info   fp64 [F][4]:    lower bound, n_iter, converged, done - zero it before the init pass; once
+ *                          done != 0 both calls leave that fit alone, so iterations can be queued
+ *                          blindly and info polled now and then;
+ *   part   fp64 [F][R][3K+1]: per-row-block sufficient statistics (sum r, sum r d, sum r d^2 per
+ *                          component with d = x - mu_k, then sum r log r), added in a fixed order.
+ * init != 0: the pass over the initial responsibilities (_base.py:121-125, _bayesian_mixture.py:
+ * 515-530): resp_inj fp64 [F][N][K] (already normalised rows) or Philox uniforms of site + f. */
+int dpc_gmm_estep(const double* x, int64_t col_stride, int64_t N, const int32_t* fit_col, int F,
+                  const double* params, int K, const double* prior, const double* info, int init,
+                  const double* resp_inj, const uint64_t* rng, uint32_t site, double* part, int R,
+                  void* stream);
+/* _m_step + _compute_lower_bound + the convergence test of fit_predict (_bayesian_mixture.py:
+ * 532-628,725-838; _base.py:247-260) for every fit that is not done. */
+int dpc_gmm_mstep(const double* part, int R, int F, int K, const double* prior, double* params,
+                  double* info, int init, double weight_concentration_prior,
+                  double mean_precision_prior, double dof_prior, double reg_covar, double tol,
+                  int max_iter, void* stream);
+
 /* ---- sample() path (DPCGANSynthesizer.sample, dp_cgan.py:838-888) ----------------------------- */
 /* sample_original_condvec (data_sampler.py:348-363): one one per row of cond at cond_st[col] +
  * argmax(table[row, st:st+dims[col]]), st = matrix_st ? matrix_st[col] : 0 (the reference's offsets
