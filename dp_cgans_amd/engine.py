@@ -95,6 +95,7 @@ def _linear_init(w, b, gen):
 class NoDist(object):
     world = 1
     rank = 0
+    active = False
 
     def allreduce(self, t):
         return t
@@ -454,7 +455,7 @@ class StepEngine(object):
         self._open = []
 
     def _allreduce(self, t):
-        if self.dist.world == 1:
+        if not self.dist.active:
             return t
         self._join()             # a collective (and a graph cut) needs every branch back on the main stream
         if self._ar_hook is not None:      # graph capture in progress: the collective runs between graph segments
@@ -609,7 +610,7 @@ class StepEngine(object):
 
     def _gen_update(self):
         g = self.gen
-        if self.dist.world > 1:
+        if self.dist.active:
             # BatchNorm gradients were formed from all-reduced column sums, i.e. are global already:
             # pre-divide so that the sum over ranks below leaves them unchanged
             for l in range(self.L):

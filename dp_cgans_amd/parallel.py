@@ -15,7 +15,10 @@ class Dist(object):
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self.active = self.world > 1
+        # DPCGAN_FORCE_DIST=1 runs the collectives even with a single rank: that is how the RCCL path
+        # (process group, all-reduce on the device, graph segments cut at the collectives) is
+        # exercised on a one-GPU box
+        self.active = self.world > 1 or os.environ.get('DPCGAN_FORCE_DIST') == '1'
         if self.active and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
@@ -40,7 +43,10 @@ class Dist(object):
 
     def barrier(self):
         if self.active:
-            dist.barrier()
+            if self.backend == 'nccl':
+                dist.barrier(device_ids=[self.local_rank])
+            else:
+                dist.barrier()
 
     def max_float(self, x, device):
         t = torch.tensor([x], dtype=torch.float64, device='cpu' if self.backend == 'gloo' else device)

@@ -110,7 +110,7 @@ def graph(dist, dev, mode):
 def main():
     mode = sys.argv[1]
     from dp_cgans_amd.parallel import Dist
-    dist = Dist(backend='gloo')
+    dist = Dist(backend=os.environ.get('DP_WORKER_BACKEND', 'gloo'))
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     if mode == 'replay':

@@ -22,12 +22,12 @@ def free_port():
     return p
 
 
-def launch(args, world=2, timeout=240):
+def launch(args, world=2, timeout=240, extra_env=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py')] + args, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -50,3 +50,17 @@ def test_two_ranks_replay_the_reference_trace():
 @pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
 def test_two_ranks_graph_segments_equal_eager(mode):
     launch(['graph', mode])
+
+
+RCCL1 = dict(DP_WORKER_BACKEND='nccl', DPCGAN_FORCE_DIST='1')
+
+
+def test_rccl_single_rank_replays_the_reference_trace():
+    """The real RCCL process group on the one GPU here (world size 1, collectives forced on): device
+    all-reduces of fp32 / fp64 buffers on the step's streams, against the reference trace."""
+    launch(['replay'], world=1, extra_env=RCCL1)
+
+
+@pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
+def test_rccl_single_rank_graph_segments_equal_eager(mode):
+    launch(['graph', mode], world=1, extra_env=RCCL1)
