@@ -420,10 +420,12 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   bool deferred_epi = false;
   if (splitk <= 0) {
     // auto: pick the K split that minimises a small cost model fitted to MI355X measurements of the
-    // 64x64 tile (tools/gemm_bench.py): a block costs 3 us + 19.5 ns per k, the chip runs 256
-    // blocks side by side (what matters is how evenly the blocks spread over the CUs: 270 blocks
-    // take as long as 512), split sums pay fp32 atomics at ~1.3 TB/s plus a memset, and a bias /
-    // activation epilogue then needs its own elementwise pass.
+    // 64x64 tile (tools/gemm_occupancy.py, tools/gemm_split_sweep.py): a CU works through its
+    // c = blocks / 256 resident blocks at 17.5 ns per k and block (21 ns when it holds only one: a
+    // single wave per SIMD hides less latency), about 1 us of prologue + epilogue each; what matters
+    // is how evenly the blocks spread over the 256 CUs (270 blocks take as long as 512).  Split sums
+    // pay fp32 atomics (~2.5 TB/s, mostly hidden behind other blocks' MFMAs) plus a memset, and a
+    // bias / activation epilogue then needs its own elementwise pass.
     splitk = 1;
     const bool can_split = !g_deterministic && (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && bm == 64 && bn == 64 && K >= 512;
     if (can_split) {
@@ -432,10 +434,11 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       int64_t maxs = K / 256;
       if (maxs > 32) maxs = 32;
       for (int64_t sp = 1; sp <= maxs; ++sp) {
-        double nb = (double)(blocks * sp);
-        double waves = nb <= 512.0 ? (double)dpc_cdiv((int64_t)nb, 256) : nb / 256.0 + 0.3;
-        double t = waves * ((double)K / sp * 0.0195 + 3.0);
-        if (sp > 1) t += (double)M * N * 4.0 * sp / 1.3e6 + (beta == 0.f ? 5.0 : 0.0) + (deferred ? 6.0 : 0.0);
+        const double nb = (double)(blocks * sp);
+        const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv((int64_t)nb, 256) : nb / 256.0 + 0.3);
+        const double rate = nb <= 256.0 ? 0.021 : 0.0175;
+        double t = c * ((double)K / sp * rate + 1.0) + 6.0;
+        if (sp > 1) t += (double)M * N * 4.0 * sp / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
         if (t < best * 0.97) { best = t; splitk = (int)sp; }    // prefer the smaller split on near ties
       }
     }

@@ -101,6 +101,36 @@ class NoDist(object):
         return t
 
 
+class GenContext(object):
+    """Buffers one generator forward writes: its inputs (z | cond inside ``Hg``, cond vector, mask and
+    the sampler's per-row picks), activations, BatchNorm statistics, the raw output ``fake`` and the
+    discriminator-input rows ``X`` [B, Dd+C] that receive the activated output and the cond vector.
+    The discriminator update and the generator update own one each, so that the generator update's
+    forward can run beside the discriminator update (StepEngine.train_step)."""
+
+    def __init__(self, eng, X):
+        d, B = eng.dev, eng.B
+        f32 = dict(device=d, dtype=torch.float32)
+        self.Hg = torch.zeros(B, eng.Wtot, **f32)
+        self.Z = [torch.zeros(B, w, **f32) for w in eng.gdim]
+        self.bn_mean = [torch.zeros(w, **f32) for w in eng.gdim]
+        self.bn_invstd = [torch.zeros(w, **f32) for w in eng.gdim]
+        ldd = (eng.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
+        self.fake = torch.zeros(B, ldd, **f32)[:, :eng.Dd]
+        self.X = X
+        self.X3 = X.view(eng.n, eng.K0)
+        self.cond = torch.zeros(B, max(eng.C, 1), **f32)
+        self.mask = torch.zeros(B, max(eng.nd, 1), device=d, dtype=torch.int32)
+        self.pair_id = torch.zeros(B, device=d, dtype=torch.int64)
+        self.val_idx = torch.zeros(B, device=d, dtype=torch.int64)
+        self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
+        self.gcount = torch.zeros(B, device=d, dtype=torch.int64)
+        maxF = max(eng.gdim + [1])
+        # one BatchNorm-sum workspace per layer (the deferred running-statistics update re-reads them)
+        self.part = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in eng.gdim]
+        self.part_R = [0] * len(eng.gdim)
+
+
 class StepEngine(object):
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
@@ -132,6 +162,7 @@ class StepEngine(object):
             weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
+        self._early_hook = None
         self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
         d = self.dev
         self.spans = torch.from_numpy(spans).to(d)
@@ -167,17 +198,17 @@ class StepEngine(object):
         # ---- activations / workspaces ----------------------------------------------------------
         B, n = self.B, self.n
         f32 = dict(device=d, dtype=torch.float32)
-        self.Hg = torch.zeros(B, self.Wtot, **f32)
         self.dHg = torch.zeros(B, self.Wtot, **f32)
-        self.Z = [torch.zeros(B, w, **f32) for w in self.gdim]
         self.dZ = [torch.zeros(B, w, **f32) for w in self.gdim]
-        self.bn_mean = [torch.zeros(w, **f32) for w in self.gdim]
-        self.bn_invstd = [torch.zeros(w, **f32) for w in self.gdim]
         ldd = (self.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
-        self.fake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
         self.dfake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
         self.Xd = torch.zeros(3 * B, self.row, **f32)
         self.Xd3 = self.Xd.view(3 * n, self.K0)
+        self.Xg = torch.zeros(B, self.row, **f32)           # discriminator input of the generator update
+        self.cd = GenContext(self, self.Xd[0:B])            # forward of the discriminator update
+        self.cg = GenContext(self, self.Xg)                 # forward of the generator update (its backward reads it)
+        self._last = self.cd
+        self.bn_scratch = [torch.zeros(2, w, **f32) for w in self.gdim]
         self.dX = torch.zeros(B, self.row, **f32)
         self.H = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
         self.S = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
@@ -203,17 +234,14 @@ class StepEngine(object):
         # graph that becomes parallel branches, which fill CUs that one small GEMM leaves idle.  Each
         # side stream has its own reduction workspace.
         self.side = [torch.cuda.Stream(device=d) for _ in range(2)] if self.dev.type == 'cuda' else []
+        # the generator update's forward (inputs, generator, activation) depends on nothing the
+        # discriminator update writes: train_step runs it on this stream beside the last discriminator update
+        self.early = torch.cuda.Stream(device=d) if self.dev.type == 'cuda' else None
         self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
         self._open = []          # side streams with work the main stream has not joined yet
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
-        self.cond = torch.zeros(B, max(self.C, 1), **f32)
-        self.mask = torch.zeros(B, max(self.nd, 1), device=d, dtype=torch.int32)
-        self.pair_id = torch.zeros(B, device=d, dtype=torch.int64)
-        self.val_idx = torch.zeros(B, device=d, dtype=torch.int64)
-        self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
-        self.gcount = torch.zeros(B, device=d, dtype=torch.int64)
         self.perm = torch.zeros(B, device=d, dtype=torch.int64)
         self.keys_ws = torch.zeros(2 * B, device=d, dtype=torch.int64)
         self.row_id = torch.zeros(B, device=d, dtype=torch.int64)
@@ -253,6 +281,17 @@ class StepEngine(object):
             _linear_init(w, b, gen)
             self.disc.P('seq.%d.weight' % (3 * i)).copy_(w)
             self.disc.P('seq.%d.bias' % (3 * i)).copy_(b)
+
+    # buffers of the latest update's generator forward (the tests and the samplers' checks read them)
+    Hg = property(lambda self: self._last.Hg)
+    fake = property(lambda self: self._last.fake)
+    fake_act = property(lambda self: self._last.X[:, :self.Dd])
+    cond = property(lambda self: self._last.cond)
+    mask = property(lambda self: self._last.mask)
+    sel = property(lambda self: self._last.sel)
+    gcount = property(lambda self: self._last.gcount)
+    pair_id = property(lambda self: self._last.pair_id)
+    val_idx = property(lambda self: self._last.val_idx)
 
     @property
     def losses(self):
@@ -305,13 +344,13 @@ class StepEngine(object):
     # ------------------------------------------------------------------------------------------
     # pieces
     # ------------------------------------------------------------------------------------------
-    def _zc(self):
+    def _zc(self, c):
         z0 = self.start[0]
-        return self.Hg[:, z0:z0 + self.E], self.Hg[:, z0 + self.E:]
+        return c.Hg[:, z0:z0 + self.E], c.Hg[:, z0 + self.E:]
 
-    def _draw_inputs(self, inj, need_real):
+    def _draw_inputs(self, inj, need_real, c):
         """z, cond vector (+ mask) and, for the discriminator update, the real rows."""
-        zv, cv = self._zc()
+        zv, cv = self._zc(c)
         B, Dd, C = self.B, self.Dd, self.C
         if 'z' in inj:
             zv.copy_(inj['z'])
@@ -327,16 +366,16 @@ class StepEngine(object):
                                     site=ops.SITE_ROWPICK + self._so)
                     ops.row_gather(self.sampler.table, self.row_id, real, Dd)
             return
-        fake_c = self.Xd[0:B, Dd:]
+        fake_c = c.X[:, Dd:]
         if 'cond' in inj:
-            self.cond.copy_(inj['cond'])
-            self.mask.copy_(inj['mask'])
-            cv.copy_(self.cond)
-            fake_c.copy_(self.cond)
+            c.cond.copy_(inj['cond'])
+            c.mask.copy_(inj['mask'])
+            cv.copy_(c.cond)
+            fake_c.copy_(c.cond)
         else:
             s = self.sampler
-            ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [self.cond, cv, fake_c], self.mask, self.pair_id,
-                                    self.val_idx, self.sel, self.gcount, pairs_inj=inj.get('pairs'),
+            ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv, fake_c], c.mask, c.pair_id,
+                                    c.val_idx, c.sel, c.gcount, pairs_inj=inj.get('pairs'),
                                     r_inj=inj.get('r'), rng=self.rng, site=ops.SITE_CONDVEC + self._so)
         if not need_real:
             return
@@ -344,51 +383,66 @@ class StepEngine(object):
         with self._fork(0):      # beside the generator forward; joined before the interpolation
             if 'real' in inj:
                 real[:, :Dd].copy_(inj['real'])
-                real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else self.cond[inj['perm']])
+                real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else c.cond[inj['perm']])
             else:
                 s = self.sampler
                 if 'perm' in inj:
                     self.perm.copy_(inj['perm'])
                 else:
                     ops.random_perm(self.rng, self.perm, self.keys_ws, site=ops.SITE_PERM + self._so)
-                ops.row_select(s.bitmaps, self.sel, self.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
+                ops.row_select(s.bitmaps, c.sel, c.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
                                rng=self.rng, cntblk=s.cntblk, site=ops.SITE_ROWPICK + self._so)
-                ops.row_gather(s.table, self.row_id, real, Dd, sel=self.sel, perm=self.perm, C=C)
+                ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=C)
 
-    def _gen_forward(self):
+    def _gen_forward(self, c, running=True):
+        """Generator forward into context ``c``.  ``running`` False leaves BatchNorm's running
+        statistics alone (``_bn_running`` applies the update later, from the column sums kept in c.part)."""
         g = self.gen
         count = float(self.gB)
         for l in range(self.L):
-            x = self.Hg[:, self.start[l]:]
-            ops.gemm(x, g.P('seq.%d.fc.weight' % l), self.Z[l], trans_b=True, bias=g.P('seq.%d.fc.bias' % l))
-            R = ops.colreduce_partial(0, self.Z[l], self.part)
+            x = c.Hg[:, self.start[l]:]
+            ops.gemm(x, g.P('seq.%d.fc.weight' % l), c.Z[l], trans_b=True, bias=g.P('seq.%d.fc.bias' % l))
+            R = ops.colreduce_partial(0, c.Z[l], c.part[l])
+            c.part_R[l] = R
             nel = R * 2 * self.gdim[l]
-            self._allreduce(self.part[:nel])
-            ops.colreduce_finish(self.part, R, 2, self.gdim[l], 0, self.bn_mean[l], self.bn_invstd[l], count=count,
-                                 run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
-                                 run_var=self.bn_run['seq.%d.bn.running_var' % l])
-            ops.bn_relu_fwd(self.Z[l], self.Hg[:, self.start[l + 1]:self.start[l]], self.bn_mean[l], self.bn_invstd[l],
+            self._allreduce(c.part[l][:nel])
+            ops.colreduce_finish(c.part[l], R, 2, self.gdim[l], 0, c.bn_mean[l], c.bn_invstd[l], count=count,
+                                 run_mean=self.bn_run['seq.%d.bn.running_mean' % l] if running else None,
+                                 run_var=self.bn_run['seq.%d.bn.running_var' % l] if running else None)
+            ops.bn_relu_fwd(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.bn_mean[l], c.bn_invstd[l],
                             g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
-        self.bn_batches += 1
-        ops.gemm(self.Hg, g.P('seq.%d.weight' % self.L), self.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
+        if running:
+            self.bn_batches += 1
+        ops.gemm(c.Hg, g.P('seq.%d.weight' % self.L), c.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
 
-    def _activate(self, inj):
-        dst = self.Xd[0:self.B, :self.Dd] if self.has_cond else self.Xd[0:self.B]
+    def _bn_running(self, c):
+        """The running-statistics update a ``_gen_forward(c, running=False)`` left out, in its place in
+        the sequence of forwards (momentum updates do not commute)."""
+        count = float(self.gB)
+        for l in range(self.L):
+            ops.colreduce_finish(c.part[l], c.part_R[l], 2, self.gdim[l], 0, self.bn_scratch[l][0], self.bn_scratch[l][1],
+                                 count=count, run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
+                                 run_var=self.bn_run['seq.%d.bn.running_var' % l])
+        self.bn_batches += 1
+
+    def _activate(self, inj, c):
+        dst = c.X[:, :self.Dd] if self.has_cond else c.X
         if self.has_cond:
-            ops.apply_activate_fwd(self.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
+            ops.apply_activate_fwd(c.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
                                    site=ops.SITE_GUMBEL + self._so)
         else:
             # no discrete columns: both networks see the raw generator output (dp_cgan.py:624-626, Q5)
-            ops.apply_activate_fwd(self.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
+            ops.apply_activate_fwd(c.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
                                    site=ops.SITE_GUMBEL + self._so)
-            dst.copy_(self.fake)
+            dst.copy_(c.fake)
 
-    def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None):
-        """Discriminator forward over rows [row0, row0+rows) of the stacked input; with ``rowscale`` the
-        head kernel also seeds the backward chain: Dl[M-1] = rowscale * w_last * S[M-1]."""
+    def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None, X3=None):
+        """Discriminator forward over rows [row0, row0+rows) of the stacked input (or of ``X3``, whose
+        results then land in rows [row0, row0+rows) of the layer buffers); with ``rowscale`` the head
+        kernel also seeds the backward chain: Dl[M-1] = rowscale * w_last * S[M-1]."""
         d, M = self.disc, self.M
         rs = slice(row0, row0 + rows)
-        x = self.Xd3[rs]
+        x = self.Xd3[rs] if X3 is None else X3
         keeps = inj.get('keep')
         for i in range(M):
             ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
@@ -407,7 +461,8 @@ class StepEngine(object):
         (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
         inj = inj or {}
         self._so = 0
-        self._draw_inputs(inj, need_real=True)
+        self._last = self.cd
+        self._draw_inputs(inj, need_real=True, c=self.cd)
         self._join()
         self._disc_forward(self.n, inj, row0=self.n, y=self.y_x)
         ops.state_advance(self.rng)
@@ -479,9 +534,12 @@ class StepEngine(object):
         self._so = 0 if sub is None else 64 * sub
         self._k = 0 if sub is None else sub
         n, B, M, d = self.n, self.B, self.M, self.disc
-        self._draw_inputs(inj, need_real=True)
-        self._gen_forward()
-        self._activate(inj)
+        self._last = self.cd
+        self._draw_inputs(inj, need_real=True, c=self.cd)
+        self._gen_forward(self.cd)
+        self._activate(inj, self.cd)
+        if self._early_hook is not None:      # see train_step
+            self._early_hook()
         self._join()
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
                         rng=self.rng, site=ops.SITE_ALPHA + self._so)
@@ -559,20 +617,31 @@ class StepEngine(object):
     def g_step(self, inj=None, update=True, sub=None):
         """One generator update (``sub``: see d_step)."""
         inj = inj or {}
+        self._g_front(inj, sub)
+        self._g_back(inj, update, sub)
+
+    def _g_front(self, inj, sub, running=True):
+        """The part of a generator update that reads nothing a discriminator update writes: zeroed
+        gradient buffer, z / cond inputs, generator forward, output activation."""
+        self._so = 0 if sub is None else 64 * sub
+        c = self.cg
+        self.gen.g.zero_()   # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
+        self._draw_inputs(inj, need_real=False, c=c)
+        self._gen_forward(c, running=running)
+        self._activate(inj, c)
+
+    def _g_back(self, inj, update, sub):
         self._so = 0 if sub is None else 64 * sub
         self._k = 0
+        self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
-        g.g.zero_()          # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
-        self._draw_inputs(inj, need_real=False)
-        self._gen_forward()
-        self._activate(inj)
-        self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g)
+        self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3)
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
         ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
         if self.has_cond:
-            ops.apply_activate_bwd(self.Xd[0:B, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
-            self._ce_parts = ops.cond_loss(self.fake, self.cond, self.mask, self.col2d, self.col2c, self.nd, None,
+            ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
+            self._ce_parts = ops.cond_loss(c.fake, c.cond, c.mask, self.col2d, self.col2c, self.nd, None,
                                            self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
         else:
             self.dfake.copy_(self.dX)
@@ -581,23 +650,23 @@ class StepEngine(object):
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
         with self._fork(0) as part:
-            ops.gemm(self.dfake, self.Hg, g.G('seq.%d.weight' % L), trans_a=True, beta=1.0)
+            ops.gemm(self.dfake, c.Hg, g.G('seq.%d.weight' % L), trans_a=True, beta=1.0)
             self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1), part=part)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
-            dy, yv = self.dHg[:, blk], self.Hg[:, blk]
-            R = ops.colreduce_partial(2, dy, self.part, y=yv, z=self.Z[l], mean=self.bn_mean[l], invstd=self.bn_invstd[l])
+            dy, yv = self.dHg[:, blk], c.Hg[:, blk]
+            R = ops.colreduce_partial(2, dy, self.part, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
             self._allreduce(self.part[:R * 2 * self.gdim[l]])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
             ops.colreduce_finish(self.part, R, 2, self.gdim[l], 2, dbeta, dgamma)
-            ops.bn_relu_bwd(dy, yv, self.Z[l], self.bn_mean[l], self.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
+            ops.bn_relu_bwd(dy, yv, c.Z[l], c.bn_mean[l], c.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
                             dgamma, count, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
             with self._fork((L - l) % 2) as part:
-                ops.gemm(self.dZ[l], self.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True, beta=1.0)
+                ops.gemm(self.dZ[l], c.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True, beta=1.0)
                 self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1), part=part)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
@@ -623,9 +692,29 @@ class StepEngine(object):
         """``d_steps`` discriminator updates and one generator update (one iteration of the
         reference's loop, dp_cgan.py:570-722), then ONE launch that advances both RNG step counters
         and both Adam step counters."""
+        overlap = self.concurrent and self.early is not None and not self.dist.active and d_steps >= 1
         for k in range(d_steps):
+            if overlap and k == d_steps - 1:
+                # the generator update's forward runs beside the rest of the last discriminator update,
+                # forked where that update's own generator forward ends (a branch forked at the start
+                # of the step is launched by the graph either ahead of the critical chain or after it);
+                # its BatchNorm running-statistics update waits for its turn (_bn_running below)
+                def issue():
+                    self._early_hook = None
+                    so = self._so
+                    self.early.wait_stream(torch.cuda.current_stream(self.dev))
+                    with torch.cuda.stream(self.early):
+                        self._g_front({}, d_steps, running=False)
+                    self._so = so
+                self._early_hook = issue
             self.d_step(sub=k)
-        self.g_step(sub=d_steps)
+        if overlap:
+            torch.cuda.current_stream(self.dev).wait_stream(self.early)
+            with self._fork(1):
+                self._bn_running(self.cg)
+            self._g_back({}, True, d_steps)
+        else:
+            self.g_step(sub=d_steps)
         ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
 
     # ------------------------------------------------------------------------------------------
@@ -633,13 +722,14 @@ class StepEngine(object):
         """Generator forward + activation for DPCGANSynthesizer.sample (BatchNorm in training mode,
         as the reference never calls .eval(): dp_cgan.py:881, Q2).  Returns the activated batch."""
         self._so = 0
-        zv, cv = self._zc()
+        self._last = c = self.cg
+        zv, cv = self._zc(c)
         ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
         if self.has_cond:
             cv.copy_(cond)
-        self._gen_forward()
+        self._gen_forward(c)
         out = torch.empty(self.B, self.Dd, device=self.dev)
-        ops.apply_activate_fwd(self.fake, out, self.spans, rng=self.rng)
+        ops.apply_activate_fwd(c.fake, out, self.spans, rng=self.rng)
         ops.state_advance(self.rng)
         return out
 

@@ -83,7 +83,7 @@ def test_engine_replays_reference_training_steps(name):
         if kind == 'D':
             eng.d_step(inj)
             close(eng.fake, tr.get(s, 'fake'), what='s%d fake' % s)
-            close(eng.Xd[0:B, :Dd], tr.get(s, 'fakeact'), what='s%d fakeact' % s)
+            close(eng.fake_act, tr.get(s, "fakeact"), what="s%d fakeact" % s)
             close(eng.y[0:n], tr.get(s, 'd_out', 0), what='s%d y_fake' % s)
             close(eng.y[n:2 * n], tr.get(s, 'd_out', 1), what='s%d y_real' % s)
             close(eng.y[2 * n:], tr.get(s, 'd_out', 2), what='s%d y_interp' % s)
@@ -106,7 +106,7 @@ def test_engine_replays_reference_training_steps(name):
         else:
             eng.g_step(inj)
             close(eng.fake, tr.get(s, 'fake'), what='s%d fake' % s)
-            close(eng.Xd[0:B, :Dd], tr.get(s, 'fakeact'), what='s%d fakeact' % s)
+            close(eng.fake_act, tr.get(s, "fakeact"), what="s%d fakeact" % s)
             close(eng.y_g, tr.get(s, 'd_out', 0), what='s%d y_fake' % s)
             losses = eng.losses.cpu().numpy()
             close(losses[3:4], [float(tr.get(s, 'ce'))], what='s%d ce' % s)
