@@ -154,35 +154,21 @@ struct Stage {
   }
 };
 
+// One block-tile segment: C[m0.., n0..] (+)= A[m0.., k_begin..k_end) * B[k_begin..k_end, n0..].
 // 256 threads = 4 waves as 2 x 2 over a BM x BN block tile; each wave owns TM x TN 32x32 MFMA tiles.
-template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+// `atomic`: add the partial sums with fp32 atomics (split-K / stream-K; epilogue and bias are then
+// applied by gemm_epilogue_kernel); otherwise store with the fused epilogue, bias if `add_bias`.
+template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS>
+__device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, const int m0, const int n0,
+                                             const int k_begin, const int k_end, const bool atomic,
+                                             const bool add_bias) {
   static_assert(!(KS && A_KC), "kscale needs an m-contiguous A");
   static_assert(PF % 2 == 0, "the LDS buffer parity is taken from the unrolled tile index");
   using SA = Stage<BM, A_KC, KS>;
   using SB = Stage<BN, B_KC>;
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
-  __shared__ __attribute__((aligned(16))) float lds[2 * SA::SIZE + 2 * SB::SIZE];
   float* As = lds;
   float* Bs = lds + 2 * SA::SIZE;
-
-  // XCD-aware remap (bijective for any grid size): ids congruent mod 8 share an XCD, give each
-  // XCD a contiguous run of tiles so neighbours along N reuse the same A panel from one L2.
-  int nwg = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
-  int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-  int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  // consecutive ids (= one XCD's run) walk the SHORTER tile axis first, so the tiles that share a
-  // panel of the larger operand sit in one L2 (a weight gradient with 4 x 77 tiles used to fetch its
-  // 60 MB activation operand once per tile row: 2x the algorithmic HBM/MALL traffic by FETCH_SIZE)
-  int tile_m, tile_n;
-  if (g.tiles_m < g.tiles_n) { tile_n = wg / g.tiles_m; tile_m = wg - tile_n * g.tiles_m; }
-  else { tile_m = wg / g.tiles_n; tile_n = wg - tile_m * g.tiles_n; }
-  int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  int k_begin = blockIdx.y * g.kchunk;
-  int k_end = min(g.K, k_begin + g.kchunk);
-  if (k_begin >= k_end && blockIdx.y > 0) return;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
@@ -277,14 +263,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // fully unroll indexes `acc` dynamically and moves all accumulators to scratch memory.)
   auto tile_out = [&](const f32x16& av, const int row0, const int col) {
     if (col < g.N) {
-      const float bv = (g.bias && blockIdx.y == 0) ? g.bias[col] : 0.f;
+      const float bv = (g.bias && add_bias) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row < g.M) {
           float v = g.alpha * av[e] + bv;
           float* cp = g.C + (int64_t)row * g.ldc + col;
-          if (g.splitk > 1) {
+          if (atomic) {
             atomicAdd(cp, v);
           } else {
             if (g.epi == EPI_LEAKY_DROPOUT) {
@@ -316,6 +302,59 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     if constexpr (TN > 1) tile_out(acc[1][1], m0 + wm0 + 32, n0 + wn0 + 32 + li);
   }
   static_assert(TM <= 2 && TN <= 2, "epilogue is written out for up to 2 x 2 MFMA tiles per wave");
+}
+
+// Tile index -> tile coordinates: consecutive ids (= one XCD's run) walk the SHORTER tile axis first,
+// so the tiles that share a panel of the larger operand sit in one L2 (a weight gradient with 4 x 77
+// tiles used to fetch its 60 MB activation operand once per tile row: 2x the algorithmic HBM/MALL
+// traffic by FETCH_SIZE).
+__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& g, int wg, int& tile_m, int& tile_n) {
+  if (g.tiles_m < g.tiles_n) { tile_n = wg / g.tiles_m; tile_m = wg - tile_n * g.tiles_m; }
+  else { tile_m = wg / g.tiles_n; tile_n = wg - tile_m * g.tiles_n; }
+}
+
+// Slot of block `bid` among `n` blocks such that the blocks of one XCD (ids congruent mod 8) hold a
+// contiguous run of slots (bijective for any n).
+__device__ __forceinline__ int gemm_xcd_slot(int bid, int n) {
+  int q = n >> 3, r = n & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Data-parallel kernel: one block per tile (gridDim.y > 1: per K chunk of a split-K product).
+template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Stage<BM, A_KC, KS>::SIZE + 2 * Stage<BN, B_KC>::SIZE];
+  int tile_m, tile_n;
+  gemm_tile_coords(g, gemm_xcd_slot(blockIdx.x, g.tiles_m * g.tiles_n), tile_m, tile_n);
+  int k_begin = blockIdx.y * g.kchunk;
+  int k_end = min(g.K, k_begin + g.kchunk);
+  if (k_begin >= k_end && blockIdx.y > 0) return;
+  gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, blockIdx.y == 0);
+}
+
+// Stream-K kernel (64x64 tiles): the tiles x K-tiles iteration space is cut into gridDim.x equal
+// contiguous runs, one per block, whatever the tile boundaries; a block adds each (partial) tile of
+// its run to C with fp32 atomics.  Every CU gets the same amount of MFMA work and pays the pipeline
+// fill once per block instead of once per tile - the shapes of the training step (48 x 4 tiles of
+// K = 4888, 4 x 11 tiles of K = 8192 ...) never divide evenly over 256 CUs otherwise.
+template <bool A_KC, bool B_KC, int PF, bool KS = false>
+__global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Stage<64, A_KC, KS>::SIZE + 2 * Stage<64, B_KC>::SIZE];
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int64_t units = (int64_t)g.tiles_m * g.tiles_n * ktiles;
+  const int slot = gemm_xcd_slot(blockIdx.x, gridDim.x);
+  int64_t u = units * slot / gridDim.x;
+  const int64_t u_end = units * (slot + 1) / gridDim.x;
+  while (u < u_end) {
+    const int tile = (int)(u / ktiles);
+    const int kt0 = (int)(u - (int64_t)tile * ktiles);
+    const int kt1 = (int)min((int64_t)ktiles, kt0 + (u_end - u));
+    int tile_m, tile_n;
+    gemm_tile_coords(g, tile, tile_m, tile_n);
+    __syncthreads();                                        // the previous segment's LDS reads are done
+    gemm_segment<64, 64, A_KC, B_KC, PF, KS>(g, lds, tile_m * 64, tile_n * 64, kt0 * BK, min(g.K, kt1 * BK), true, false);
+    u += kt1 - kt0;
+  }
 }
 
 // Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
@@ -373,6 +412,27 @@ static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st)
   else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF>), grid, block, 0, st, g);
 }
 
+template <int PF>
+static void launch_streamk(const GemmArgs& g, bool a_kc, bool b_kc, int nblocks, hipStream_t st) {
+  dim3 grid(nblocks), block(256);
+  if (g.kscale) {
+    if (b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<false, true, PF, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_streamk_kernel<false, false, PF, true>), grid, block, 0, st, g);
+    return;
+  }
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<true, true, PF>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<true, false, PF>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<false, true, PF>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_streamk_kernel<false, false, PF>), grid, block, 0, st, g);
+}
+
+static int g_streamk_blocks = 0;     // tuning hook: 0 = automatic, -1 = never, n = use n blocks whenever allowed
+extern "C" int dpc_gemm_streamk_config(int blocks) {
+  if (blocks < -1 || blocks > 4096) return DPC_EINVAL;
+  g_streamk_blocks = blocks;
+  return DPC_OK;
+}
+
 extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
                             const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
                             const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
@@ -418,48 +478,53 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   g.tiles_n = (int)dpc_cdiv(N, bn);
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
   bool deferred_epi = false;
+  int streamk = 0;                  // > 0: number of blocks of a stream-K launch
   if (splitk <= 0) {
-    // auto: pick the K split that minimises a small cost model fitted to MI355X measurements of the
-    // 64x64 tile (tools/gemm_occupancy.py, tools/gemm_split_sweep.py): a CU works through its
-    // c = blocks / 256 resident blocks at 17.5 ns per k and block (21 ns when it holds only one: a
-    // single wave per SIMD hides less latency), about 1 us of prologue + epilogue each; what matters
-    // is how evenly the blocks spread over the 256 CUs (270 blocks take as long as 512).  Split sums
-    // pay fp32 atomics (~2.5 TB/s, mostly hidden behind other blocks' MFMAs) plus a memset, and a
-    // bias / activation epilogue then needs its own elementwise pass.
+    // auto.  Cost model fitted to MI355X measurements of the 64x64 tile (tools/gemm_occupancy.py,
+    // tools/gemm_split_sweep.py): a CU works through its resident blocks at 17.5 ns per k and block
+    // (21 ns when it holds only one: a single wave per SIMD hides less latency).  One block per tile
+    // spreads `blocks` tiles over 256 CUs - 270 tiles take as long as 512 - while stream-K cuts
+    // tiles x K into equal runs and pays fp32 atomics (~2.5 TB/s, mostly hidden behind other
+    // blocks' MFMAs), a memset, and a separate pass for a bias / activation epilogue.
     splitk = 1;
     const bool can_split = !g_deterministic && (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && bm == 64 && bn == 64 && K >= 512;
-    if (can_split) {
+    if (can_split && g_streamk_blocks >= 0) {
       const bool deferred = (epi != EPI_NONE || bias);
-      double best = 1e30;
-      int64_t maxs = K / 256;
-      if (maxs > 32) maxs = 32;
-      for (int64_t sp = 1; sp <= maxs; ++sp) {
-        const double nb = (double)(blocks * sp);
-        const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv((int64_t)nb, 256) : nb / 256.0 + 0.3);
-        const double rate = nb <= 256.0 ? 0.021 : 0.0175;
-        double t = c * ((double)K / sp * rate + 1.0) + 6.0;
-        if (sp > 1) t += (double)M * N * 4.0 * sp / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
-        if (t < best * 0.97) { best = t; splitk = (int)sp; }    // prefer the smaller split on near ties
-      }
+      const double nb = (double)blocks;
+      const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv(blocks, 256) : nb / 256.0 + 0.3);
+      const double t_plain = c * ((double)K * (nb <= 256.0 ? 0.021 : 0.0175) + 1.0) + 6.0;
+      const double kblocks = nb * (double)dpc_cdiv(K, BK) * BK;          // k per block summed over all tiles
+      // measured (tools/gemm_streamk_sweep.py): few tiles -> one block per CU, else 2-3 per CU
+      const int sk_blocks = blocks < 64 ? 256 : (kblocks >= 768.0 * 256.0 ? 768 : (kblocks >= 512.0 * 128.0 ? 512 : 256));
+      const double t_sk = kblocks / 256.0 * (sk_blocks > 256 ? 0.0175 : 0.021) + 3.0 + 6.0 +
+                          (double)M * N * 4.0 * (1.0 + sk_blocks / nb) / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
+      if (g_streamk_blocks > 0) streamk = g_streamk_blocks;
+      else if (t_sk < 0.95 * t_plain) streamk = sk_blocks;
     }
   }
   if (splitk > 1 && (epi != EPI_NONE || bias)) {
     DPC_CHECK_ARG(beta == 0.f, "gemm: split-K with an epilogue needs beta == 0");
     deferred_epi = true;
   }
+  if (streamk > 0 && (epi != EPI_NONE || bias)) deferred_epi = true;
   DPC_CHECK_ARG(splitk == 1 || beta == 0.f || beta == 1.f, "gemm: split-K needs beta in {0,1}");
   g.splitk = splitk;
   int ktiles = (int)dpc_cdiv(K, BK);
   g.kchunk = (int)dpc_cdiv(ktiles, splitk) * BK;
   if (K == 0) g.kchunk = BK;
-  if (splitk > 1 && beta == 0.f) {
+  if ((splitk > 1 || streamk > 0) && beta == 0.f) {
     hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
     if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
     g.beta = 1.f;   // accumulate into the zeroed C
   }
   GemmArgs full = g;
   if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; }
-  if (bm == 128 && bn == 128) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
+  if (streamk > 0) {
+    int64_t units = blocks * ktiles;
+    if (streamk > units) streamk = (int)units;
+    launch_streamk<2>(g, a_kc, b_kc, streamk, st);
+  }
+  else if (bm == 128 && bn == 128) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
   else if (bm == 128) launch_tile<128, 64, 2>(g, a_kc, b_kc, st);
   else if (bn == 128) launch_tile<64, 128, 2>(g, a_kc, b_kc, st);
   else launch_tile<64, 64, 2>(g, a_kc, b_kc, st);

@@ -68,6 +68,9 @@ int dpc_gemm_config(int force_tile);
 /* reproducible mode: no automatic split-K (its fp32 atomics make the last bits order-dependent);
  * every other kernel of the library is bit-reproducible already.  Host-side state. */
 int dpc_set_deterministic(int on);
+/* Tuning hook of the automatic stream-K choice: 0 automatic, -1 never, n > 0 always with n blocks
+ * (wherever fp32 atomics are allowed: not in deterministic mode, beta in {0,1}). */
+int dpc_gemm_streamk_config(int blocks);
 
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
 /* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)

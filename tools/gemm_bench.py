@@ -27,39 +27,46 @@ SHAPES = [  # (tag, M, N, K, trans_a, trans_b, epi)
 if len(sys.argv) > 1 and sys.argv[1] == 'big':
     SHAPES = [('big NT', 4096, 4096, 4096, False, True, 0), ('big NN', 4096, 4096, 4096, False, False, 0),
               ('big TN', 4096, 4096, 4096, True, False, 0), ('mid NT', 8192, 1024, 1024, False, True, 0)]
-rng = ops.new_rng(1, dev)
-tot_ms, tot_fl = 0.0, 0.0
-from dp_cgans_amd._lib import lib
-TILES = [0]
-if len(sys.argv) > 1 and sys.argv[1] == 'tiles':
-    TILES = [0, 64, 12864, 64128, 128]
-for tag, M, N, K, ta, tb, epi in [sh for sh in SHAPES for _ in TILES]:
-    def mat(r, c):      # rows padded to 16 bytes, as the engine's buffers are
-        return torch.randn(r, (c + 3) // 4 * 4, device=dev)[:, :c]
-    A = mat(K, M) if ta else mat(M, K)
-    B = mat(N, K) if tb else mat(K, N)
-    C = torch.zeros(M, N, device=dev)
-    aux = torch.ones(M, N, device=dev)
-    kw = {}
-    if epi == 1:
-        kw = dict(epi=1, aux_out=aux, rng=rng, site=20, bias=torch.zeros(N, device=dev))
-    elif epi == 2:
-        kw = dict(epi=2, aux_in=aux)
-    tile = TILES[0]
-    TILES.append(TILES.pop(0))
-    lib().cdll.dpc_gemm_config(tile)
-    tag = '%s t%-5d' % (tag, tile)
-    for _ in range(3):
-        ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    fl = 2.0 * M * N * K
-    tot_ms += ms
-    tot_fl += fl
-    print('%-22s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s' % (tag, M, N, K, ms * 1e3, fl / ms / 1e9))
-print('sum %.1f us, %.1f TF/s aggregate' % (tot_ms * 1e3, tot_fl / tot_ms / 1e9))
+
+
+def main():
+    rng = ops.new_rng(1, dev)
+    tot_ms, tot_fl = 0.0, 0.0
+    from dp_cgans_amd._lib import lib
+    TILES = [0]
+    if len(sys.argv) > 1 and sys.argv[1] == 'tiles':
+        TILES = [0, 64, 12864, 64128, 128]
+    for tag, M, N, K, ta, tb, epi in [sh for sh in SHAPES for _ in TILES]:
+        def mat(r, c):      # rows padded to 16 bytes, as the engine's buffers are
+            return torch.randn(r, (c + 3) // 4 * 4, device=dev)[:, :c]
+        A = mat(K, M) if ta else mat(M, K)
+        B = mat(N, K) if tb else mat(K, N)
+        C = torch.zeros(M, N, device=dev)
+        aux = torch.ones(M, N, device=dev)
+        kw = {}
+        if epi == 1:
+            kw = dict(epi=1, aux_out=aux, rng=rng, site=20, bias=torch.zeros(N, device=dev))
+        elif epi == 2:
+            kw = dict(epi=2, aux_in=aux)
+        tile = TILES[0]
+        TILES.append(TILES.pop(0))
+        lib().cdll.dpc_gemm_config(tile)
+        tag = '%s t%-5d' % (tag, tile)
+        for _ in range(3):
+            ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        fl = 2.0 * M * N * K
+        tot_ms += ms
+        tot_fl += fl
+        print('%-22s M=%5d N=%5d K=%5d  %8.1f us  %6.1f TF/s' % (tag, M, N, K, ms * 1e3, fl / ms / 1e9))
+    print('sum %.1f us, %.1f TF/s aggregate' % (tot_ms * 1e3, tot_fl / tot_ms / 1e9))
+
+
+if __name__ == '__main__':
+    main()
