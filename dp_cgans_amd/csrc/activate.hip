@@ -19,6 +19,32 @@ __global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restri
     float* yr = y + b * ldy + off;
     if (kind == 0) {
       for (int j = 0; j < dim; ++j) yr[j] = tanhf(xr[j]);
+    } else if (dim <= 16) {
+      // the span lives in registers (same operations in the same order as the general path below,
+      // which keeps its intermediate values in y and pays a store -> load round trip per pass)
+      float t[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < dim) {
+          float e = en ? en[b * ld_en + off + j]
+                       : -logf(dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j))));
+          t[j] = (xr[j] - logf(e)) * inv_tau;
+          mx = fmaxf(mx, t[j]);
+        }
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < dim) {
+          t[j] = expf(t[j] - mx);
+          sum += t[j];
+        }
+      }
+      float inv = 1.f / sum;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < dim) yr[j] = t[j] * inv;
     } else {
       float mx = -INFINITY;
       for (int j = 0; j < dim; ++j) {
@@ -72,6 +98,26 @@ __global__ __launch_bounds__(256) void activate_bwd_kernel(const float* __restri
       for (int j = 0; j < dim; ++j) {
         float v = gr[j] * (1.f - yr[j] * yr[j]);
         dr[j] = accumulate ? dr[j] + v : v;
+      }
+    } else if (dim <= 16) {
+      float yv[16], gv[16];
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < dim) {
+          yv[j] = yr[j];
+          gv[j] = gr[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < dim) dot += yv[j] * gv[j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < dim) {
+          float v = inv_tau * yv[j] * (gv[j] - dot);
+          dr[j] = accumulate ? dr[j] + v : v;
+        }
       }
     } else {
       float dot = 0.f;

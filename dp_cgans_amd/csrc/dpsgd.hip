@@ -30,14 +30,31 @@ __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, cons
     const float4* a = reinterpret_cast<const float4*>(r0);
     const float4* b = reinterpret_cast<const float4*>(r1);
     const float4* c = reinterpret_cast<const float4*>(r2);
-    for (int j = threadIdx.x; j < (len >> 2); j += blockDim.x) {
-      float4 x = a[j], y = b[j], z = c[j];
+    const int n4 = len >> 2, bd = blockDim.x;
+    auto fma6 = [&](const float4& x, const float4& y, const float4& z) {
       g[0] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
       g[1] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       g[2] += x.x * z.x + x.y * z.y + x.z * z.z + x.w * z.w;
       g[3] += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
       g[4] += y.x * z.x + y.y * z.y + y.z * z.z + y.w * z.w;
       g[5] += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+    };
+    int j = threadIdx.x;
+    // four positions (12 loads) in flight per thread: with a few thousand examples per batch the
+    // launch is a few blocks per CU and nothing else hides the memory latency
+    for (; j + 3 * bd < n4; j += 4 * bd) {
+      float4 x0 = a[j], y0 = b[j], z0 = c[j];
+      float4 x1 = a[j + bd], y1 = b[j + bd], z1 = c[j + bd];
+      float4 x2 = a[j + 2 * bd], y2 = b[j + 2 * bd], z2 = c[j + 2 * bd];
+      float4 x3 = a[j + 3 * bd], y3 = b[j + 3 * bd], z3 = c[j + 3 * bd];
+      fma6(x0, y0, z0);
+      fma6(x1, y1, z1);
+      fma6(x2, y2, z2);
+      fma6(x3, y3, z3);
+    }
+    for (; j < n4; j += bd) {
+      float4 x = a[j], y = b[j], z = c[j];
+      fma6(x, y, z);
     }
   } else {
     for (int j = threadIdx.x; j < len; j += blockDim.x) {

@@ -262,16 +262,33 @@ extern "C" int dpc_disc_seed(const float* rowscale, const float* w, const float*
 
 // xhat rows of the stacked discriminator input: out = a*real + (1-a)*fake with one a per pac group
 // (pac consecutive rows of length rowlen).  alpha_inj[g] or Philox draw g; alpha_out optional.
+// One grid row (blockIdx.y) per pac group: alpha is drawn once per thread, not once per element, and
+// the rows move as 16-byte vectors when the group length allows.
+template <bool VEC>
 __global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
                                                           float* __restrict__ out, int64_t n, int64_t group_len,
                                                           const float* __restrict__ alpha_inj, const uint64_t* rng,
                                                           uint32_t site, float* alpha_out) {
-  int64_t total = n * group_len;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t g = i / group_len;
-    float a = alpha_inj ? alpha_inj[g] : dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)g));
-    out[i] = a * real[i] + (1.f - a) * fake[i];
-    if (alpha_out && i == g * group_len) alpha_out[g] = a;
+  for (int64_t g = blockIdx.y; g < n; g += gridDim.y) {
+    const float a = alpha_inj ? alpha_inj[g] : dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)g));
+    const int64_t base = g * group_len;
+    if (VEC) {
+      const float4* r4 = reinterpret_cast<const float4*>(real + base);
+      const float4* f4 = reinterpret_cast<const float4*>(fake + base);
+      float4* o4 = reinterpret_cast<float4*>(out + base);
+      for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < (group_len >> 2); j += (int64_t)gridDim.x * blockDim.x) {
+        float4 r = r4[j], f = f4[j], o;
+        o.x = a * r.x + (1.f - a) * f.x;
+        o.y = a * r.y + (1.f - a) * f.y;
+        o.z = a * r.z + (1.f - a) * f.z;
+        o.w = a * r.w + (1.f - a) * f.w;
+        o4[j] = o;
+      }
+    } else {
+      for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < group_len; j += (int64_t)gridDim.x * blockDim.x)
+        out[base + j] = a * real[base + j] + (1.f - a) * fake[base + j];
+    }
+    if (alpha_out && blockIdx.x == 0 && threadIdx.x == 0) alpha_out[g] = a;
   }
 }
 
@@ -280,28 +297,65 @@ extern "C" int dpc_interpolate(const float* real, const float* fake, float* out,
                                void* stream) {
   DPC_CHECK_ARG(real && fake && out && n > 0 && group_len > 0, "interpolate: bad argument");
   DPC_CHECK_ARG(alpha_inj || rng, "interpolate: no random source");
-  hipLaunchKernelGGL(interpolate_kernel, dim3(dpc_grid(n * group_len, 256)), dim3(256), 0, (hipStream_t)stream, real,
-                     fake, out, n, group_len, alpha_inj, rng, site, alpha_out);
+  const bool vec = (group_len % 4 == 0) && ((((uintptr_t)real | (uintptr_t)fake | (uintptr_t)out) & 15) == 0);
+  const int64_t per_row = vec ? group_len / 4 : group_len;
+  int64_t gx = dpc_cdiv(per_row, 256);
+  if (gx > 8) gx = 8;
+  dim3 grid((unsigned)gx, (unsigned)(n < 65535 ? n : 65535));
+  if (vec)
+    hipLaunchKernelGGL(interpolate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, real, fake, out, n, group_len,
+                       alpha_inj, rng, site, alpha_out);
+  else
+    hipLaunchKernelGGL(interpolate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, real, fake, out, n, group_len,
+                       alpha_inj, rng, site, alpha_out);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
 
 // Gradient-penalty row pass, in place: g0[r,:] -> v0[r,:] = coef * (nrm-1)/nrm * g0[r,:],
 // coef = 2*lambda/n_total; pen_rows[r] = (nrm-1)^2; nrm_out[r] = nrm.  One block per row.
+// One block per row.  VEC: the row (up to 8 float4 per thread = 8192 floats) stays in registers
+// between the norm and the scaling pass, all loads issued before the first use.
+template <bool VEC>
 __global__ __launch_bounds__(256) void gp_norm_kernel(float* __restrict__ g0, int64_t ld, int64_t n, int K0, float coef,
                                                       double* __restrict__ pen_rows, float* __restrict__ nrm_out) {
   __shared__ double red[16];
   for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
     float* row = g0 + r * ld;
     double acc = 0.0;
-    for (int j = threadIdx.x; j < K0; j += blockDim.x) {
-      float v = row[j];
-      acc += (double)v * (double)v;
+    float4 c[8];
+    if (VEC) {
+      const float4* r4 = reinterpret_cast<const float4*>(row);
+      const int n4 = K0 >> 2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = threadIdx.x + q * 256;
+        c[q] = j < n4 ? r4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        acc += (double)c[q].x * (double)c[q].x + (double)c[q].y * (double)c[q].y + (double)c[q].z * (double)c[q].z +
+               (double)c[q].w * (double)c[q].w;
+    } else {
+      for (int j = threadIdx.x; j < K0; j += blockDim.x) {
+        float v = row[j];
+        acc += (double)v * (double)v;
+      }
     }
     double tot = dpc_block_sum(acc, red);
     float nrm = (float)sqrt(tot);
     float f = nrm > 0.f ? coef * (nrm - 1.f) / nrm : 0.f;
-    for (int j = threadIdx.x; j < K0; j += blockDim.x) row[j] *= f;
+    if (VEC) {
+      float4* r4 = reinterpret_cast<float4*>(row);
+      const int n4 = K0 >> 2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = threadIdx.x + q * 256;
+        if (j < n4) r4[j] = make_float4(c[q].x * f, c[q].y * f, c[q].z * f, c[q].w * f);
+      }
+    } else {
+      for (int j = threadIdx.x; j < K0; j += blockDim.x) row[j] *= f;
+    }
     if (threadIdx.x == 0) {
       pen_rows[r] = (double)(nrm - 1.f) * (double)(nrm - 1.f);
       if (nrm_out) nrm_out[r] = nrm;
@@ -313,8 +367,13 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(float* __restrict__ g0, in
 extern "C" int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef, double* pen_rows, float* nrm_out,
                            void* stream) {
   DPC_CHECK_ARG(g0 && pen_rows && n > 0 && K0 > 0 && ld >= K0, "gp_norm: bad argument");
-  hipLaunchKernelGGL(gp_norm_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, g0, ld, n,
-                     K0, coef, pen_rows, nrm_out);
+  const bool vec = (K0 % 4 == 0) && (K0 <= 8192) && (ld % 4 == 0) && (((uintptr_t)g0 & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(gp_norm_kernel<true>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, g0,
+                       ld, n, K0, coef, pen_rows, nrm_out);
+  else
+    hipLaunchKernelGGL(gp_norm_kernel<false>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, g0,
+                       ld, n, K0, coef, pen_rows, nrm_out);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

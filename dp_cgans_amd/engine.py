@@ -163,6 +163,7 @@ class StepEngine(object):
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
         self._early_hook = None
+        self._inline = False
         self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
         d = self.dev
         self.spans = torch.from_numpy(spans).to(d)
@@ -352,11 +353,13 @@ class StepEngine(object):
         """z, cond vector (+ mask) and, for the discriminator update, the real rows."""
         zv, cv = self._zc(c)
         B, Dd, C = self.B, self.Dd, self.C
-        if 'z' in inj:
-            zv.copy_(inj['z'])
-        else:
-            ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z + self._so, 0.0, 1.0)
+        with self._fork(1):      # the latent draw beside the cond-vector sampling
+            if 'z' in inj:
+                zv.copy_(inj['z'])
+            else:
+                ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z + self._so, 0.0, 1.0)
         if not self.has_cond:
+            self._join()
             if need_real:     # uniform rows (data_sampler.py:388-390)
                 real = self.Xd[B:2 * B]
                 if 'real' in inj:
@@ -377,6 +380,7 @@ class StepEngine(object):
             ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv, fake_c], c.mask, c.pair_id,
                                     c.val_idx, c.sel, c.gcount, pairs_inj=inj.get('pairs'),
                                     r_inj=inj.get('r'), rng=self.rng, site=ops.SITE_CONDVEC + self._so)
+        self._join()
         if not need_real:
             return
         real = self.Xd[B:2 * B]
@@ -484,7 +488,7 @@ class StepEngine(object):
 
         def __enter__(self):
             e = self.eng
-            if not e.concurrent or not e.side:
+            if not e.concurrent or not e.side or e._inline:
                 self.ctx = None
                 return e.part
             side = e.side[self.k]
@@ -504,6 +508,8 @@ class StepEngine(object):
         return StepEngine._Fork(self, k)
 
     def _join(self):
+        if self._inline:         # issuing the early branch: it forks nothing, and the open forks belong to the main stream
+            return
         main = torch.cuda.current_stream(self.dev)
         for side in self._open:
             main.wait_stream(side)
@@ -703,8 +709,12 @@ class StepEngine(object):
                     self._early_hook = None
                     so = self._so
                     self.early.wait_stream(torch.cuda.current_stream(self.dev))
-                    with torch.cuda.stream(self.early):
-                        self._g_front({}, d_steps, running=False)
+                    self._inline = True
+                    try:
+                        with torch.cuda.stream(self.early):
+                            self._g_front({}, d_steps, running=False)
+                    finally:
+                        self._inline = False
                     self._so = so
                 self._early_hook = issue
             self.d_step(sub=k)
