@@ -324,12 +324,19 @@ __device__ __forceinline__ int gemm_xcd_slot(int bid, int n) {
 template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2 * Stage<BM, A_KC, KS>::SIZE + 2 * Stage<BN, B_KC>::SIZE];
+  // 1-D grid of tiles x splitk blocks.  An XCD's contiguous run of slots is taken in split-major order
+  // (slot = split * tiles + tile): with 8 or more K chunks an XCD works on ONE chunk of K for all
+  // tiles, so each XCD's L2 fetches its slice of A and B once - the whole product then reads A and B
+  // about once from HBM instead of once per tile row / column and XCD.
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int slot = gemm_xcd_slot(blockIdx.x, tiles * g.splitk);
+  const int split = slot / tiles;
   int tile_m, tile_n;
-  gemm_tile_coords(g, gemm_xcd_slot(blockIdx.x, g.tiles_m * g.tiles_n), tile_m, tile_n);
-  int k_begin = blockIdx.y * g.kchunk;
+  gemm_tile_coords(g, slot - split * tiles, tile_m, tile_n);
+  int k_begin = split * g.kchunk;
   int k_end = min(g.K, k_begin + g.kchunk);
-  if (k_begin >= k_end && blockIdx.y > 0) return;
-  gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, blockIdx.y == 0);
+  if (k_begin >= k_end && split > 0) return;
+  gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, split == 0);
 }
 
 // Stream-K kernel (64x64 tiles): the tiles x K-tiles iteration space is cut into gridDim.x equal
@@ -400,7 +407,7 @@ extern "C" int dpc_gemm_config(int force_tile) {
 
 template <int BM, int BN, int PF>
 static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
-  dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(256);
+  dim3 grid(g.tiles_m * g.tiles_n * g.splitk), block(256);
   if (g.kscale) {     // validated by the caller: A is m-contiguous
     if (b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF, true>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF, true>), grid, block, 0, st, g);
@@ -426,7 +433,10 @@ static void launch_streamk(const GemmArgs& g, bool a_kc, bool b_kc, int nblocks,
   else hipLaunchKernelGGL((gemm_streamk_kernel<false, false, PF>), grid, block, 0, st, g);
 }
 
-static int g_streamk_blocks = 0;     // tuning hook: 0 = automatic, -1 = never, n = use n blocks whenever allowed
+// Stream-K is an option, not the default: on the step's shapes it is ~4 % faster than the XCD-aware
+// split-K below (perfect balance) but fetches 2.7x the bytes from beyond L2 - its runs put different
+// K ranges of a panel on an XCD at the same time (G dWout: 268 MB against 59 MB, 41 MB algorithmic).
+static int g_streamk_blocks = -1;    // -1 = never (split-K), 0 = automatic, n = use n blocks whenever allowed
 extern "C" int dpc_gemm_streamk_config(int blocks) {
   if (blocks < -1 || blocks > 4096) return DPC_EINVAL;
   g_streamk_blocks = blocks;
@@ -500,6 +510,20 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
                           (double)M * N * 4.0 * (1.0 + sk_blocks / nb) / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
       if (g_streamk_blocks > 0) streamk = g_streamk_blocks;
       else if (t_sk < 0.95 * t_plain) streamk = sk_blocks;
+    } else if (can_split) {
+      // split-K: tiles x sp blocks, each tile's K range cut into sp equal chunks
+      const bool deferred = (epi != EPI_NONE || bias);
+      double best = 1e30;
+      int64_t maxs = K / 256;
+      if (maxs > 32) maxs = 32;
+      for (int64_t sp = 1; sp <= maxs; ++sp) {
+        const double nb = (double)(blocks * sp);
+        const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv((int64_t)nb, 256) : nb / 256.0 + 0.3);
+        const double rate = nb <= 256.0 ? 0.021 : 0.0175;
+        double t = c * ((double)K / sp * rate + 1.0) + 6.0;
+        if (sp > 1) t += (double)M * N * 4.0 * sp / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
+        if (t < best * 0.97) { best = t; splitk = (int)sp; }    // prefer the smaller split on near ties
+      }
     }
   }
   if (splitk > 1 && (epi != EPI_NONE || bias)) {

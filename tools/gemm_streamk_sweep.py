@@ -1,5 +1,5 @@
 """Stream-K block-count sweep for the GEMM shapes of the T1M step, with a correctness check against
-torch (fp64 reference).  -1 = one block per tile (no atomics)."""
+torch (fp64 reference).  -1 = automatic split-K (XCD-aware block order), 0 = automatic stream-K."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +33,7 @@ for tag, M, N, K, ta, tb, epi in SHAPES:
     elif epi == 2:
         ref = ref * aux.double()
     line = []
-    for nb in (-1, 0, 256, 512, 768, 1024):
+    for nb in (-1, 0, 512, 768):
         lib().cdll.dpc_gemm_streamk_config(nb)
         for _ in range(2):
             ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
