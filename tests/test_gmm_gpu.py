@@ -103,3 +103,20 @@ def test_transformer_fit_uses_the_device_mixtures():
     assert enc.shape == (n, t.output_dimensions) and np.abs(enc[:, 0]).max() <= 0.99
     back = t.inverse_transform(enc)
     assert list(back.columns) == ['a', 'b', 'k'] and (back['k'] == df['k']).all()
+
+
+def test_two_valued_column():
+    """A column with two distinct values (components collapse onto spikes; covariances fall back to
+    reg_covar): same iterations and parameters as the oracle.  (A strictly constant column has a zero
+    covariance prior; its dead components' covariances are nk-sized rounding residue in sklearn as
+    well, so there is nothing to pin there.)"""
+    from dp_cgans_amd.gmm_fit import DeviceBayesianGMM
+    n, K = 256, 4
+    rng = np.random.default_rng(4)
+    x = (rng.integers(0, 2, n).astype(np.float64) * 7.0)[None]
+    rs = np.random.RandomState(9)
+    resp = gmm.random_resp(rs, n, K)[None, None]
+    fit = DeviceBayesianGMM(n_components=K, n_init=1, device=DEV).fit_columns(x, resp_inj=resp)[0]
+    check(fit, gmm.fit(x[0], [resp[0, 0]]))
+    const = DeviceBayesianGMM(n_components=K, n_init=1, device=DEV).fit_columns(np.full((1, n), 3.25))[0]
+    assert np.isfinite(const.means).all() and abs(const.weights.sum() - 1) < 1e-12     # runs, stays finite
