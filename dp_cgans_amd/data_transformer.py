@@ -41,7 +41,7 @@ class OneHotCategories(object):
 
     def decode(self, onehot):
         idx = np.argmax(onehot, axis=1)
-        return pd.Series([self.dummies[i] for i in idx])
+        return pd.Series(np.asarray(self.dummies, dtype=object)[idx])
 
 
 class GaussianMixtureTable(object):
