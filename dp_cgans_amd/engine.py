@@ -239,9 +239,11 @@ class StepEngine(object):
         # discriminator update writes: train_step runs it on this stream beside the last discriminator update
         self.early = torch.cuda.Stream(device=d) if self.dev.type == 'cuda' else None
         self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
+        self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
+        self.pair_forwards = True    # data-parallel train_step: one BatchNorm all-reduce per layer for both forwards
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
         self.perm = torch.zeros(B, device=d, dtype=torch.int64)
         self.keys_ws = torch.zeros(2 * B, device=d, dtype=torch.int64)
@@ -419,6 +421,31 @@ class StepEngine(object):
             self.bn_batches += 1
         ops.gemm(c.Hg, g.P('seq.%d.weight' % self.L), c.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
 
+    def _gen_forward_pair(self, ca, cb):
+        """Two generator forwards in lockstep (the last discriminator update's and the generator
+        update's: same weights, different inputs) for data-parallel steps: the BatchNorm column sums of
+        both go into ONE buffer and ONE all-reduce per layer instead of two.  Same arithmetic and the
+        same running-statistics order (ca then cb) as two _gen_forward calls."""
+        g = self.gen
+        count = float(self.gB)
+        for l in range(self.L):
+            F = self.gdim[l]
+            W, b = g.P('seq.%d.fc.weight' % l), g.P('seq.%d.fc.bias' % l)
+            R = 0
+            for i, c in enumerate((ca, cb)):          # same shape, hence the same R: the two sets lie back to back
+                ops.gemm(c.Hg[:, self.start[l]:], W, c.Z[l], trans_b=True, bias=b)
+                R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
+            self._allreduce(self.pair_part[:2 * R * 2 * F])
+            for i, c in enumerate((ca, cb)):
+                ops.colreduce_finish(self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, 2, F, 0, c.bn_mean[l],
+                                     c.bn_invstd[l], count=count, run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
+                                     run_var=self.bn_run['seq.%d.bn.running_var' % l])
+                ops.bn_relu_fwd(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.bn_mean[l], c.bn_invstd[l],
+                                g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
+        self.bn_batches += 2
+        for c in (ca, cb):
+            ops.gemm(c.Hg, g.P('seq.%d.weight' % self.L), c.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
+
     def _bn_running(self, c):
         """The running-statistics update a ``_gen_forward(c, running=False)`` left out, in its place in
         the sequence of forwards (momentum updates do not commute)."""
@@ -538,14 +565,19 @@ class StepEngine(object):
         from call sites offset by 64*sub and leaves the single end-of-step advance to the caller."""
         inj = inj or {}
         self._so = 0 if sub is None else 64 * sub
-        self._k = 0 if sub is None else sub
-        n, B, M, d = self.n, self.B, self.M, self.disc
-        self._last = self.cd
         self._draw_inputs(inj, need_real=True, c=self.cd)
         self._gen_forward(self.cd)
         self._activate(inj, self.cd)
         if self._early_hook is not None:      # see train_step
             self._early_hook()
+        self._d_back(inj, update, sub)
+
+    def _d_back(self, inj, update, sub):
+        """Everything of a discriminator update after its generator forward + activation."""
+        self._so = 0 if sub is None else 64 * sub
+        self._k = 0 if sub is None else sub
+        n, B, M, d = self.n, self.B, self.M, self.disc
+        self._last = self.cd
         self._join()
         ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
                         rng=self.rng, site=ops.SITE_ALPHA + self._so)
@@ -699,6 +731,25 @@ class StepEngine(object):
         reference's loop, dp_cgan.py:570-722), then ONE launch that advances both RNG step counters
         and both Adam step counters."""
         overlap = self.concurrent and self.early is not None and not self.dist.active and d_steps >= 1
+        if self.dist.active and self.pair_forwards and d_steps >= 1:
+            # data parallel: the two generator forwards of the step's tail share their collectives
+            for k in range(d_steps - 1):
+                self.d_step(sub=k)
+            last = d_steps - 1
+            self._so = 64 * last
+            self._draw_inputs({}, need_real=True, c=self.cd)
+            self._so = 64 * d_steps
+            self.gen.g.zero_()
+            self._draw_inputs({}, need_real=False, c=self.cg)
+            self._gen_forward_pair(self.cd, self.cg)
+            self._so = 64 * last
+            self._activate({}, self.cd)
+            self._so = 64 * d_steps
+            self._activate({}, self.cg)
+            self._d_back({}, True, last)
+            self._g_back({}, True, d_steps)
+            ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
+            return
         for k in range(d_steps):
             if overlap and k == d_steps - 1:
                 # the generator update's forward runs beside the rest of the last discriminator update,

@@ -92,15 +92,21 @@ def graph(dist, dev, mode):
         return eng
     from dp_cgans_amd import ops as _ops
     _ops.set_deterministic(True)      # bit-equality below needs the atomics-free GEMM path
-    a, b = make(), make()
+    a, b, c = make(), make(), make()
+    c.pair_forwards = False           # two separate generator forwards (one all-reduce per layer each)
     for _ in range(4):
         a.train_step(1)
+        c.train_step(1)
     gs = GraphStep(b, d_steps=1)
     for _ in range(4):
         gs.run()
     torch.cuda.synchronize()
     assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
     assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)
+    assert torch.equal(a.disc.p, c.disc.p) and torch.equal(a.gen.p, c.gen.p), 'paired forwards changed the step'
+    sa, sc = a.generator_state_dict(), c.generator_state_dict()
+    for k in sa:
+        assert torch.equal(sa[k].cpu(), sc[k].cpu()), k
     chk = a.disc.p.clone()
     dist.allreduce(chk)
     assert torch.equal(chk, a.disc.p * dist.world), 'replicas diverged'
