@@ -9,7 +9,9 @@ Memory layout (all fp32, row-major, resident in HBM for the whole fit):
   disc params / grads / Adam m,v  one flat buffer each
   Hg  [B, sum(g)+E+C]             generator activations, concat-free: [h_{L-1} | .. | h_0 | z | c];
                                   layer l reads the suffix that starts after its own output block,
-                                  which is exactly torch.cat([out, input]) of Residual (dp_cgan.py:83)
+                                  which is exactly torch.cat([out, input]) of Residual (dp_cgan.py:83).
+                                  Two sets (GenContext): one for the discriminator update's forward,
+                                  one for the generator update's, which runs beside the former
   Xd  [3B, Dd+C] = [3n, K0]       stacked discriminator input: rows 0..n-1 fake groups, n..2n-1 real
                                   groups, 2n..3n-1 interpolates (later overwritten by the penalty's
                                   v-chain so that one GEMM per layer yields loss + penalty weight grads)
