@@ -570,8 +570,6 @@ class StepEngine(object):
         self._draw_inputs(inj, need_real=True, c=self.cd)
         self._gen_forward(self.cd)
         self._activate(inj, self.cd)
-        if self._early_hook is not None:      # see train_step
-            self._early_hook()
         self._d_back(inj, update, sub)
 
     def _d_back(self, inj, update, sub):
@@ -585,6 +583,8 @@ class StepEngine(object):
                         rng=self.rng, site=ops.SITE_ALPHA + self._so)
         self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
         self._loss_dirty[0] = True
+        if self._early_hook is not None:      # see train_step
+            self._early_hook()
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
         self._disc_chain_down(3 * n, self.rowscale_d)
         W1 = d.P('seq.0.weight')
@@ -754,11 +754,16 @@ class StepEngine(object):
             return
         for k in range(d_steps):
             if overlap and k == d_steps - 1:
-                # the generator update's forward runs beside the rest of the last discriminator update,
-                # forked where that update's own generator forward ends (a branch forked at the start
-                # of the step is launched by the graph either ahead of the critical chain or after it);
+                # the generator update's forward runs beside the tail of the last discriminator update
+                # (the penalty chain, the clip factors, the weight gradients: many small kernels, while
+                # beside the big first-layer GEMMs it would only take CUs from them);
                 # its BatchNorm running-statistics update waits for its turn (_bn_running below)
                 def issue():
+                    # forked where the discriminator forward ends.  (How the graph runtime maps branches
+                    # to its 4 hardware queues depends on the capture order: issued a few kernels later
+                    # the branch lands behind the bias-gradient reductions and overlaps nothing; forked
+                    # before the first-layer GEMM it takes CUs from it.  Measured: 1.124 ms here,
+                    # 1.137 / 1.219 ms for those two.)
                     self._early_hook = None
                     so = self._so
                     self.early.wait_stream(torch.cuda.current_stream(self.dev))
