@@ -241,8 +241,8 @@ class DataTransformer(object):
             if info.column_type == 'continuous':
                 cols.append(host[:, j])
             else:
-                dummies = info.transform.dummies
-                cols.append(pd.Series([dummies[int(i)] for i in host[:, j]]).to_numpy())
+                dummies = np.asarray(info.transform.dummies, dtype=object)     # labels by category index
+                cols.append(pd.Series(dummies[host[:, j].astype(np.int64)]).infer_objects().to_numpy())
             names.append(info.column_name)
         recovered = pd.DataFrame(dict(zip(names, cols)), columns=names).astype(self._column_raw_dtypes)
         return recovered if self.dataframe else recovered.values
