@@ -24,11 +24,12 @@ __global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restri
       // which keeps its intermediate values in y and pays a store -> load round trip per pass)
       float t[16];
       float mx = -INFINITY;
+      const uint64_t zero2[2] = {0, 0};
+      DpcDrawCache dc(en ? zero2 : rng, site);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j < dim) {
-          float e = en ? en[b * ld_en + off + j]
-                       : -logf(dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j))));
+          float e = en ? en[b * ld_en + off + j] : -logf(dpc_u32_to_unit(dc.draw((uint64_t)(b * Dd + off + j))));
           t[j] = (xr[j] - logf(e)) * inv_tau;
           mx = fmaxf(mx, t[j]);
         }

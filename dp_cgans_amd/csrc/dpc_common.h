@@ -78,6 +78,26 @@ __device__ __forceinline__ uint32_t dpc_draw_u32(const uint64_t* rng, uint32_t s
   return (l & 2u) ? hi : lo;
 }
 
+// The same draws for a thread that walks consecutive indices: the Philox block is recomputed only
+// when idx crosses into the next group of four (a 10-round Philox per element made the activation
+// kernel ALU-bound).
+struct DpcDrawCache {
+  uint64_t seed, step, cur;
+  uint32_t site;
+  DpcPhilox4 p;
+  __device__ __forceinline__ DpcDrawCache(const uint64_t* rng, uint32_t site_) : seed(rng[0]), step(rng[1]), cur(~0ull), site(site_) {}
+  __device__ __forceinline__ uint32_t draw(uint64_t idx) {
+    const uint64_t blk = idx >> 2;
+    if (blk != cur) {
+      p = dpc_philox(seed, step, site, blk);
+      cur = blk;
+    }
+    const uint32_t l = (uint32_t)idx & 3u;
+    uint32_t lo = (l & 1u) ? p.v[1] : p.v[0], hi = (l & 1u) ? p.v[3] : p.v[2];
+    return (l & 2u) ? hi : lo;
+  }
+};
+
 // (0,1) open interval, 23 bits: k + 0.5 for k < 2^23 is exact in fp32, so neither 0 nor 1 can come
 // out (with 24 bits the largest value would round up to 1.0 and -log(-log(u)) would be +inf).
 __device__ __forceinline__ float dpc_u32_to_unit(uint32_t x) { return ((x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
