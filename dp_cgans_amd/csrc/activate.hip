@@ -6,14 +6,18 @@
 #include "dpc_common.h"
 
 // span table rows: (offset, dim, kind) kind 0 = tanh, 1 = gumbel-softmax
+// IT: index type of the flattened (row, span) loop; uint32_t whenever it fits (a 64-bit division per
+// thread is ~100 instructions, which showed in a kernel that does ~15 elements per row and span)
+template <typename IT>
 __global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                            int64_t ldy, const int32_t* __restrict__ spans, int nspan,
                                                            int64_t B, int Dd, const float* __restrict__ en, int64_t ld_en,
                                                            const uint64_t* rng, uint32_t site, float inv_tau) {
-  int64_t total = B * nspan;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = idx / nspan;
-    int s = (int)(idx - b * nspan);
+  const IT total = (IT)B * (IT)nspan, stride = (IT)gridDim.x * blockDim.x;
+  for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const IT bq = idx / (IT)nspan;
+    const int64_t b = (int64_t)bq;
+    int s = (int)(idx - bq * (IT)nspan);
     int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
     const float* xr = x + b * ldx + off;
     float* yr = y + b * ldy + off;
@@ -74,23 +78,29 @@ extern "C" int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int
   DPC_CHECK_ARG(exp_noise || rng, "apply_activate_fwd: no noise source");
   DPC_CHECK_ARG(B >= 0 && nspan >= 0 && ldx >= Dd && ldy >= Dd && tau > 0.f, "apply_activate_fwd: bad shape");
   if (B == 0 || nspan == 0) return DPC_OK;
-  hipLaunchKernelGGL(activate_fwd_kernel, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                     y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
+  if (B * nspan < (1LL << 31))
+    hipLaunchKernelGGL(activate_fwd_kernel<uint32_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
+  else
+    hipLaunchKernelGGL(activate_fwd_kernel<int64_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
 
 // dx = dL/dx given y (saved activations) and dy.  tanh: dy (1 - y^2); softmax((x+g)/tau):
 // (1/tau) y (dy - sum_j y_j dy_j).  accumulate != 0 adds into dx.
+template <typename IT>
 __global__ __launch_bounds__(256) void activate_bwd_kernel(const float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ dy, int64_t lddy,
                                                            float* __restrict__ dx, int64_t lddx,
                                                            const int32_t* __restrict__ spans, int nspan, int64_t B,
                                                            float inv_tau, int accumulate) {
-  int64_t total = B * nspan;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = idx / nspan;
-    int s = (int)(idx - b * nspan);
+  const IT total = (IT)B * (IT)nspan, stride = (IT)gridDim.x * blockDim.x;
+  for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const IT bq = idx / (IT)nspan;
+    const int64_t b = (int64_t)bq;
+    int s = (int)(idx - bq * (IT)nspan);
     int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
     const float* yr = y + b * ldy + off;
     const float* gr = dy + b * lddy + off;
@@ -137,8 +147,12 @@ extern "C" int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* 
   DPC_CHECK_ARG(y && dy && dx && spans, "apply_activate_bwd: null pointer");
   DPC_CHECK_ARG(B >= 0 && nspan >= 0 && tau > 0.f, "apply_activate_bwd: bad shape");
   if (B == 0 || nspan == 0) return DPC_OK;
-  hipLaunchKernelGGL(activate_bwd_kernel, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy,
-                     dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
+  if (B * nspan < (1LL << 31))
+    hipLaunchKernelGGL(activate_bwd_kernel<uint32_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                       ldy, dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
+  else
+    hipLaunchKernelGGL(activate_bwd_kernel<int64_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                       ldy, dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -151,6 +165,7 @@ extern "C" int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* 
 // Block partial sums go to `partials[gridDim.x]`; cond_loss_finish adds them in index order
 // (bit-reproducible) and scales.
 // ---------------------------------------------------------------------------------------------
+template <typename IT>
 __global__ __launch_bounds__(256) void cond_loss_kernel(const float* __restrict__ fake, int64_t ldf,
                                                         const float* __restrict__ cond, int64_t ldc,
                                                         const int32_t* __restrict__ mask, int64_t ldm,
@@ -160,10 +175,11 @@ __global__ __launch_bounds__(256) void cond_loss_kernel(const float* __restrict_
                                                         int accumulate, double* __restrict__ partials) {
   __shared__ double red[16];
   double acc = 0.0;
-  int64_t total = B * Dd;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = idx / Dd;
-    int j = (int)(idx - b * Dd);
+  const IT total = (IT)B * (IT)Dd, stride = (IT)gridDim.x * blockDim.x;
+  for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const IT bq = idx / (IT)Dd;
+    const int64_t b = (int64_t)bq;
+    int j = (int)(idx - bq * (IT)Dd);
     int d = col2d[j];
     float gval = 0.f;
     if (d >= 0) {
@@ -208,8 +224,12 @@ extern "C" int dpc_cond_loss(const float* fake, int64_t ldf, const float* cond, 
   if (B_total <= 0) B_total = B;      // data parallel: B rows of a global batch of B_total
   float scale = (float)(2.0 / ((double)B_total * (double)nd));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cond_loss_kernel, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d, col2c, B,
-                     Dd, scale, dfake, lddf, accumulate, partials);
+  if (B * Dd < (1LL << 31))
+    hipLaunchKernelGGL(cond_loss_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d,
+                       col2c, B, Dd, scale, dfake, lddf, accumulate, partials);
+  else
+    hipLaunchKernelGGL(cond_loss_kernel<int64_t>, dim3(grid), dim3(256), 0, st, fake, ldf, cond, ldc, mask, ldm, col2d,
+                       col2c, B, Dd, scale, dfake, lddf, accumulate, partials);
   if (n_used) *n_used = grid;          // the caller may sum partials[0 : grid] * 2/(B_total*nd) later (dpc_sum_f64)
   if (loss_out)
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 2.0 / ((double)B_total * (double)nd), loss_out);
