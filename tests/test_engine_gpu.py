@@ -137,12 +137,46 @@ def test_engine_sampler_path_matches_oracle_on_same_draws():
     from dp_cgans_amd import ops
     from dp_cgans_amd.data_sampler import DataSampler
     from dp_cgans_amd.engine import StepEngine
-    from oracle import nets as onets
     z = load('adult_sampler.npz')
-    enc, span = z['encoded'], z['span_info']
+    _check_step_against_oracle(z['encoded'], z['span_info'], 24, (40, 24), (48, 16), 120, 10)
+
+
+def _synthetic_table(rng, n_rows, cont_modes, disc_dims):
+    """Encoded matrix + span_info: continuous columns (value, one-hot of `m` modes), then discrete ones."""
+    cols, span = [], []
+    for m in cont_modes:
+        cols.append(np.clip(rng.normal(0, 0.4, (n_rows, 1)), -0.99, 0.99))
+        cols.append(np.eye(m)[rng.integers(m, size=n_rows)])
+        span += [(1, 0, 2), (m, 1, 2)]
+    for k in disc_dims:
+        p = rng.dirichlet(np.ones(k) * 2.0)
+        cols.append(np.eye(k)[rng.choice(k, size=n_rows, p=p)])
+        span.append((k, 1, 1))
+    return np.concatenate(cols, axis=1), np.array(span, dtype=np.int32)
+
+
+@pytest.mark.parametrize('cfg', [
+    # E, generator dims, discriminator dims, batch, pac, continuous modes, discrete dims
+    dict(E=7, g=(37,), d=(21,), B=36, pac=3, cont=(1, 3), disc=(2, 5)),                   # one hidden layer each, odd sizes
+    dict(E=16, g=(24, 8, 40), d=(32, 12, 20), B=64, pac=1, cont=(2,), disc=(3, 17, 2)),    # three layers, pac 1, a 17-way span
+    dict(E=5, g=(9, 11), d=(13, 6), B=20, pac=10, cont=(), disc=(2, 2, 4)),                # discrete columns only
+    dict(E=32, g=(64, 64), d=(64, 64), B=512, pac=8, cont=(1, 2, 3, 1), disc=(2, 3, 4, 6, 8)),
+])
+def test_step_against_oracle_on_odd_shapes(cfg):
+    """The Philox-driven step against the CPU oracle on table / network shapes that exercise the
+    unaligned and edge paths (row lengths not multiples of 4, single layers, pac 1, wide spans)."""
+    rng = np.random.default_rng(len(cfg['disc']) * 7 + cfg['B'])
+    enc, span = _synthetic_table(rng, 400, cfg['cont'], cfg['disc'])
+    _check_step_against_oracle(enc, span, cfg['E'], cfg['g'], cfg['d'], cfg['B'], cfg['pac'])
+
+
+def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac):
+    from dp_cgans_amd import ops
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import nets as onets
     dev = torch.device('cuda:0')
-    B, E, pac = 120, 24, 10
-    eng = StepEngine(span, E, (40, 24), (48, 16), B, pac, dev, private=False, seed=5)
+    eng = StepEngine(span, E, gdim, ddim, B, pac, dev, private=False, seed=5)
     eng.sampler = DataSampler(enc, span, device=dev)
     gp = {k: v.cpu() for k, v in eng.gen.state_dict().items()}
     dp = {k: v.cpu() for k, v in eng.disc.state_dict().items()}
