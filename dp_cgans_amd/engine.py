@@ -458,16 +458,18 @@ class StepEngine(object):
                                  run_var=self.bn_run['seq.%d.bn.running_var' % l])
         self.bn_batches += 1
 
-    def _activate(self, inj, c):
-        dst = c.X[:, :self.Dd] if self.has_cond else c.X
-        if self.has_cond:
-            ops.apply_activate_fwd(c.fake, dst, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
+    def _activate(self, inj, c, raw=False):
+        """Activated generator output -> the discriminator-input rows of ``c``.  ``raw``: a table
+        without discrete columns feeds the RAW generator output to the discriminator in the
+        discriminator update (dp_cgan.py:624-626, Q5) - but the activated one in the generator update
+        (:699-702)."""
+        if self.has_cond or not raw:
+            ops.apply_activate_fwd(c.fake, c.X[:, :self.Dd], self.spans, exp_noise=inj.get('exp'), rng=self.rng,
                                    site=ops.SITE_GUMBEL + self._so)
         else:
-            # no discrete columns: both networks see the raw generator output (dp_cgan.py:624-626, Q5)
             ops.apply_activate_fwd(c.fake, self.dfake, self.spans, exp_noise=inj.get('exp'), rng=self.rng,
-                                   site=ops.SITE_GUMBEL + self._so)
-            dst.copy_(c.fake)
+                                   site=ops.SITE_GUMBEL + self._so)      # computed and dropped, as the reference does
+            c.X.copy_(c.fake)
 
     def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None, X3=None):
         """Discriminator forward over rows [row0, row0+rows) of the stacked input (or of ``X3``, whose
@@ -569,7 +571,7 @@ class StepEngine(object):
         self._so = 0 if sub is None else 64 * sub
         self._draw_inputs(inj, need_real=True, c=self.cd)
         self._gen_forward(self.cd)
-        self._activate(inj, self.cd)
+        self._activate(inj, self.cd, raw=True)
         self._d_back(inj, update, sub)
 
     def _d_back(self, inj, update, sub):
@@ -679,12 +681,10 @@ class StepEngine(object):
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
         ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
+        ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
         if self.has_cond:
-            ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
             self._ce_parts = ops.cond_loss(c.fake, c.cond, c.mask, self.col2d, self.col2c, self.nd, None,
                                            self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
-        else:
-            self.dfake.copy_(self.dX)
         # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
@@ -745,7 +745,7 @@ class StepEngine(object):
             self._draw_inputs({}, need_real=False, c=self.cg)
             self._gen_forward_pair(self.cd, self.cg)
             self._so = 64 * last
-            self._activate({}, self.cd)
+            self._activate({}, self.cd, raw=True)
             self._so = 64 * d_steps
             self._activate({}, self.cg)
             self._d_back({}, True, last)

@@ -206,8 +206,11 @@ def d_step_grads(gp, dp, span_info, pac, z, cond, perm, real, exp_noise, masks_f
     gpl = {k: v.detach().clone().requires_grad_(True) for k, v in gp.items()}
     fake = gen_forward(gpl, torch.cat([z, cond], 1), bn_state)
     fakeact = apply_activate(fake, span_info, exp_noise)
-    fake_cat = torch.cat([fakeact, cond], 1)
-    real_cat = torch.cat([real, cond[perm]], 1)
+    if cond.shape[1] > 0:
+        fake_cat = torch.cat([fakeact, cond], 1)
+        real_cat = torch.cat([real, cond[perm]], 1)
+    else:               # no discrete columns: the RAW generator output goes to D (dp_cgan.py:621-626, Q5)
+        fake_cat, real_cat = fake, real
     y_fake = disc_forward(dpl, fake_cat, pac, masks_fake)
     y_real = disc_forward(dpl, real_cat, pac, masks_real)
     loss_d = -(y_real.mean() - y_fake.mean())
@@ -234,7 +237,10 @@ def g_step_grads(gp, dp, span_info, pac, z, cond, mask, exp_noise, masks_d, bn_s
     fake = gen_forward(gpl, torch.cat([z, cond], 1), bn_state)
     fakeact = apply_activate(fake, span_info, exp_noise)
     y_fake = disc_forward(dp, torch.cat([fakeact, cond], 1), pac, masks_d)
-    ce = (cond_loss_pair_loop if loop_loss else cond_loss_closed)(fake, cond, mask, span_info)
+    if cond.shape[1] > 0:
+        ce = (cond_loss_pair_loop if loop_loss else cond_loss_closed)(fake, cond, mask, span_info)
+    else:               # condvec_pair is None: cross_entropy_pair = 0 (dp_cgan.py:708-709)
+        ce = torch.zeros(())
     loss_g = -y_fake.mean() + ce
     keys = list(gpl.keys())
     gs = torch.autograd.grad(loss_g, [gpl[k] for k in keys])

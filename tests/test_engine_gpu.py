@@ -161,6 +161,7 @@ def _synthetic_table(rng, n_rows, cont_modes, disc_dims):
     dict(E=16, g=(24, 8, 40), d=(32, 12, 20), B=64, pac=1, cont=(2,), disc=(3, 17, 2)),    # three layers, pac 1, a 17-way span
     dict(E=5, g=(9, 11), d=(13, 6), B=20, pac=10, cont=(), disc=(2, 2, 4)),                # discrete columns only
     dict(E=32, g=(64, 64), d=(64, 64), B=512, pac=8, cont=(1, 2, 3, 1), disc=(2, 3, 4, 6, 8)),
+    dict(E=12, g=(20, 16), d=(24, 8), B=40, pac=4, cont=(2, 1, 3), disc=()),               # no discrete columns (Q5)
 ])
 def test_step_against_oracle_on_odd_shapes(cfg):
     """The Philox-driven step against the CPU oracle on table / network shapes that exercise the
@@ -199,14 +200,17 @@ def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac):
     # ---- discriminator update
     e, zz, keeps, al = draws(3 * n)
     eng.d_step()
-    cond = eng.cond.cpu()
-    perm = eng.perm.cpu()
     real = eng.Xd[B:2 * B, :Dd].cpu()
     rid = eng.row_id.cpu().numpy()
     assert np.array_equal(real.numpy(), enc[rid].astype(np.float32))
-    sel = eng.sel.cpu().numpy()[perm.numpy()]
-    cat_col = eng.sampler.cat_col.cpu().numpy()
-    assert (enc[rid, cat_col[sel[:, 0]]] == 1).all() and (enc[rid, cat_col[sel[:, 1]]] == 1).all()
+    if eng.has_cond:
+        cond = eng.cond.cpu()
+        perm = eng.perm.cpu()
+        sel = eng.sel.cpu().numpy()[perm.numpy()]
+        cat_col = eng.sampler.cat_col.cpu().numpy()
+        assert (enc[rid, cat_col[sel[:, 0]]] == 1).all() and (enc[rid, cat_col[sel[:, 1]]] == 1).all()
+    else:               # no discrete columns: no cond vector, uniformly drawn rows
+        cond, perm = torch.zeros(B, 0), torch.arange(B)
     out = onets.d_step_grads(gp, dp, span, pac, zz, cond, perm, real, e, [k[0:n] for k in keeps],
                              [k[n:2 * n] for k in keeps], [k[2 * n:] for k in keeps], al)
     losses = eng.losses.cpu().numpy()
@@ -222,7 +226,7 @@ def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac):
     # ---- generator update
     e, zz, keeps, al = draws(n)
     eng.g_step()
-    cond, mask = eng.cond.cpu(), eng.mask.cpu()
+    cond, mask = (eng.cond.cpu(), eng.mask.cpu()) if eng.has_cond else (torch.zeros(B, 0), torch.zeros(B, 0, dtype=torch.int32))
     out = onets.g_step_grads(gp, dp2, span, pac, zz, cond, mask, e, keeps)
     losses = eng.losses.cpu().numpy()
     close([losses[2] + losses[3]], [float(out['loss_g'])], what='loss_g')
