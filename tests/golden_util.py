@@ -40,6 +40,7 @@ class Trace(object):
         self.kinds = []
         for s in range(self.n_steps):
             self.kinds.append('D' if ('s%d/pen/0' % s) in z.files else 'G')
+        self.has_cond = 's0/cond/0' in z.files        # False for a table without discrete columns (trace_num)
 
     def get(self, s, name, j=0):
         return self.z['s%d/%s/%d' % (s, name, j)]

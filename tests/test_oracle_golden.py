@@ -24,7 +24,7 @@ def tt(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
-@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz'])
+@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz', 'trace_num.npz'])
 def test_training_steps_match_reference(name):
     tr = Trace(name)
     assert tr.kinds == ['D', 'D', 'G', 'D', 'D', 'G']
@@ -41,11 +41,11 @@ def test_training_steps_match_reference(name):
     B = tr.B
     for s, kind in enumerate(tr.kinds):
         z = tt(tr.get(s, 'normal'))
-        cond = tt(tr.get(s, 'cond'))
+        cond = tt(tr.get(s, 'cond')) if tr.has_cond else torch.zeros(B, 0)
         expn = tt(tr.exp_full(s))
         masks = [[tt(m) for m in grp] for grp in tr.masks(s)]
         if kind == 'D':
-            perm = tt(tr.get(s, 'shuffle').astype(np.int64))
+            perm = tt(tr.get(s, 'shuffle').astype(np.int64)) if tr.has_cond else torch.arange(B)
             real = tt(tr.get(s, 'real').astype(np.float32))
             alpha = tt(tr.get(s, 'rand').reshape(-1))
             out = onets.d_step_grads(gp, dp, tr.span_info, tr.pac, z, cond, perm, real, expn,
@@ -74,11 +74,12 @@ def test_training_steps_match_reference(name):
             if tr.private:
                 dp = {k: v.clamp(-0.01, 0.01) for k, v in dp.items()}   # dp_cgan.py:657-661
         else:
-            mask = tt(tr.get(s, 'mask'))
+            mask = tt(tr.get(s, 'mask')) if tr.has_cond else torch.zeros(B, 0, dtype=torch.int32)
             out = onets.g_step_grads(gp, dp, tr.span_info, tr.pac, z, cond, mask, expn, masks[0], bn)
             close(out['fake'], tr.get(s, 'fake'), what='fake')
             close(out['fakeact'], tr.get(s, 'fakeact'), what='fakeact')
-            close(out['ce'], tr.get(s, 'ce'), what='ce')
+            if tr.has_cond:
+                close(out['ce'], tr.get(s, 'ce'), what='ce')
             close(out['loss_g'], tr.get(s, 'backward_value', 0), what='loss_g')
             ref_g = tr.params(s, 'g')
             for k in tr.gkeys:

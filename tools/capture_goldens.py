@@ -275,7 +275,7 @@ def gm_params(gm):
         precisions_cholesky=gm.precisions_cholesky_.reshape(-1))
 
 
-def run_trace(private, out_path, csv):
+def run_trace(private, out_path, csv, numeric_only=False):
     import pandas as pd
     import torch
     from dp_cgans import DP_CGAN
@@ -285,6 +285,8 @@ def run_trace(private, out_path, csv):
     np.random.seed(0)
     torch.manual_seed(0)
     df = pd.read_csv(csv)
+    if numeric_only:          # a table without discrete columns (no cond vector, raw output to D)
+        df = df.select_dtypes('number')
     model = DP_CGAN(epochs=1, batch_size=100, generator_dim=(48, 32), discriminator_dim=(32, 24),
                     embedding_dim=16, discriminator_steps=2, pac=10, private=private, cuda=False,
                     verbose=False)
@@ -429,6 +431,9 @@ def main():
             for f in os.listdir(tmp):
                 os.remove(os.path.join(tmp, f))
             run_trace(True, os.path.join(out, 'trace_priv.npz'), csv)
+            for f in os.listdir(tmp):
+                os.remove(os.path.join(tmp, f))
+            run_trace(False, os.path.join(out, 'trace_num.npz'), csv, numeric_only=True)
         finally:
             os.chdir(cwd)
     for f in sorted(os.listdir(out)):
