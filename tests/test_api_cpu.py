@@ -120,3 +120,15 @@ def test_validation_errors():
         s._validate_discrete_columns([[1, 2]], [])
     with pytest.raises(ValueError, match='Invalid columns found'):
         s._validate_discrete_columns(np.zeros((3, 2)), [5])
+
+
+def test_host_inverse_transform_against_reference_fixture():
+    """DataTransformer.inverse_transform (host path, data_transformer.py:152-213) on the matrix the
+    reference inverted when tests/golden/adult_sample.npz was captured: identical values."""
+    from golden_util import load
+    from test_api_gpu import golden_transformer
+    ze, zf = load('adult_encode.npz'), load('adult_sample.npz')
+    tr, _ = golden_transformer(ze, 'cpu')
+    back = tr.inverse_transform(zf['inv/in'].astype(np.float64))
+    assert list(back.columns) == [str(c) for c in zf['inv/columns']]
+    np.testing.assert_array_equal(back.to_numpy(dtype=np.float64), zf['inv/out'])

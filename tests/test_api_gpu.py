@@ -216,3 +216,23 @@ def test_sample_path_kernels_match_the_host_restatement():
     for c in host.columns:
         assert host[c].dtype == devd[c].dtype, c
         assert np.array_equal(host[c].to_numpy(), devd[c].to_numpy()), c
+
+
+def test_sample_path_against_reference_fixture():
+    """SURVEY 8f-1 pinned to the reference: sample_original_condvec with the reference's recorded randint
+    draws (cond vectors bit-exact, zero-offset quirk Q9 included) and inverse_transform of a
+    generated-looking matrix (argmax over the valid components, clip to +-1, de-normalise), on the
+    device kernel and on the host path."""
+    from dp_cgans_amd.data_sampler import DataSampler
+    ze, zs, zf = load('adult_encode.npz'), load('adult_sampler.npz'), load('adult_sample.npz')
+    ds = DataSampler(zs['encoded'], zs['span_info'], device='cuda:0')
+    cond = ds.sample_original_condvec(len(zf['soc/rows']), rows=zf['soc/rows'], cols=zf['soc/cols'])
+    assert cond.dtype == np.float32 and np.array_equal(cond, zf['soc/cond'])
+    tr, _ = golden_transformer(ze, 'cuda:0')
+    gen = zf['inv/in']
+    want = zf['inv/out']
+    host = tr.inverse_transform(gen.astype(np.float64))
+    assert list(host.columns) == [str(c) for c in zf['inv/columns']]
+    np.testing.assert_array_equal(host.to_numpy(dtype=np.float64), want)
+    dev = tr.inverse_transform_device(torch.from_numpy(gen).to('cuda:0'))
+    np.testing.assert_array_equal(dev.to_numpy(dtype=np.float64), want)

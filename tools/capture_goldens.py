@@ -393,6 +393,40 @@ def capture_encode_and_sampler(outdir, csv):
     sm['call/row_ids'] = np.array(b['choice'][B:2 * B], dtype=np.int64)     # picked row ids
     sm['call/real'] = real
     np.savez_compressed(os.path.join(outdir, 'adult_sampler.npz'), **sm)
+
+    # sample() path: sample_original_condvec with its randint draws recorded, and
+    # inverse_transform of a generated-looking matrix (values beyond +-1 to exercise the clip).
+    sp = {}
+    drawn = []
+    real_randint = np.random.randint
+
+    def randint(*a, **k):
+        v = real_randint(*a, **k)
+        drawn.append(int(v))
+        return v
+    np.random.seed(11)
+    np.random.randint = randint
+    try:
+        cond = ds.sample_original_condvec(128)
+    finally:
+        np.random.randint = real_randint
+    sp['soc/rows'] = np.array(drawn[0::2], dtype=np.int64)
+    sp['soc/cols'] = np.array(drawn[1::2], dtype=np.int64)
+    sp['soc/cond'] = cond
+    rs = np.random.RandomState(3)
+    Dd = enc['encoded'].shape[1]
+    gen = rs.rand(96, Dd)
+    st = 0
+    for col in tr.output_info_list:
+        if len(col) == 2:                                   # continuous: value in (-1.3, 1.3)
+            gen[:, st] = rs.uniform(-1.3, 1.3, 96)
+        st += sum(x.dim for x in col)
+    gen = gen.astype(np.float32)
+    back = tr.inverse_transform(gen.astype(np.float64))
+    sp['inv/in'] = gen
+    sp['inv/out'] = back.to_numpy(dtype=np.float64)
+    sp['inv/columns'] = np.array(list(back.columns))
+    np.savez_compressed(os.path.join(outdir, 'adult_sample.npz'), **sp)
     return synth
 
 
