@@ -391,3 +391,56 @@ def test_overlapped_generator_forward_equals_the_sequential_step(d_steps):
         for k in sa:
             assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
     _ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(E=7, g=(37,), d=(21,), B=36, pac=3, cont=(1, 3), disc=(2, 5)),
+    dict(E=16, g=(24, 8, 40), d=(32, 12, 20), B=64, pac=1, cont=(2,), disc=(3, 17, 2)),
+    dict(E=32, g=(64, 64), d=(64, 64), B=512, pac=8, cont=(1, 2, 3, 1), disc=(2, 3, 4, 6, 8)),
+])
+def test_dpsgd_against_oracle_on_odd_shapes(cfg):
+    """DP-SGD discriminator update, Philox-driven, against the per-example autograd loop on shapes with
+    unaligned rows, one / three layers and pac 1: per-example norms, clip factors (bound at the median
+    norm), clipped mean gradient."""
+    from dp_cgans_amd import ops
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import dpsgd
+    rng = np.random.default_rng(len(cfg['disc']) * 7 + cfg['B'])
+    enc, span = _synthetic_table(rng, 400, cfg['cont'], cfg['disc'])
+    dev = torch.device('cuda:0')
+    B, E, pac = cfg['B'], cfg['E'], cfg['pac']
+
+    def run(clip):
+        eng = StepEngine(span, E, cfg['g'], cfg['d'], B, pac, dev, private=True, dp_mode='dpsgd', dp_clip=clip, seed=5)
+        eng.sampler = DataSampler(enc, span, device=dev)
+        gp = {k: v.cpu() for k, v in eng.gen.state_dict().items()}
+        dp = {k: v.cpu() for k, v in eng.disc.state_dict().items()}
+        n, Dd = eng.n, eng.Dd
+        e = torch.empty(B, Dd, device=dev)
+        ops.fill(e, ops.FILL_EXP, eng.rng, ops.SITE_GUMBEL)
+        zz = torch.empty(B, E, device=dev)
+        ops.fill(zz, ops.FILL_NORMAL, eng.rng, ops.SITE_Z)
+        keeps = []
+        for i, w in enumerate(eng.ddim):
+            kb = torch.empty(3 * n, w, dtype=torch.uint8, device=dev)
+            ops.fill(kb, ops.FILL_KEEP, eng.rng, ops.SITE_DROP0 + i)
+            keeps.append(kb.cpu())
+        al = torch.empty(n, device=dev)
+        ops.fill(al, ops.FILL_UNIFORM, eng.rng, ops.SITE_ALPHA)
+        eng.d_step(update=False)
+        mk = lambda g: [k[g * n:(g + 1) * n] for k in keeps]
+        out = dpsgd.d_step_grads_dpsgd(gp, dp, span, pac, zz.cpu(), eng.cond.cpu(), eng.perm.cpu(),
+                                       eng.Xd[B:2 * B, :Dd].cpu(), e.cpu(), mk(0), mk(1), mk(2), al.cpu(), clip=clip)
+        return eng, out
+
+    eng, out = run(1e30)
+    close(eng.norms, out['norms'], what='per-example gradient norms')
+    clip = float(np.median(out['norms'].numpy()))
+    eng, out = run(clip)                          # same seeds, same draws
+    n = eng.n
+    close(eng.norms, out['norms'], what='per-example gradient norms')
+    close(eng.rowc[0:n], out['factors'], what='clip factors')
+    assert float(eng.rowc.min()) < 1.0 and float(eng.rowc.max()) == 1.0
+    for k in eng.disc.keys:
+        close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='clipped mean grad ' + k)
