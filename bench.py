@@ -117,6 +117,14 @@ def main():
             eng.concurrent = True
             prof = ops.GEMM_PROFILE
             ops.GEMM_PROFILE = None
+            if os.environ.get('DPC_GEMM_BREAKDOWN'):      # per-shape launch times of one step, to stderr
+                per = {}
+                for i, (e0, e1, f, shp) in enumerate(prof):
+                    per.setdefault((i % (len(prof) // nprof), shp), []).append(e0.elapsed_time(e1) * 1e3)
+                for (i, shp), v in sorted(per.items()):
+                    us = sum(v) / len(v)
+                    sys.stderr.write('%2d M=%5d N=%5d K=%5d ta=%d tb=%d  %7.1f us %6.1f TF/s\n'
+                                     % (i, shp[0], shp[1], shp[2], shp[3], shp[4], us, 2e-6 * shp[0] * shp[1] * shp[2] / us))
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
             flops = sum(f for _, _, f, _ in prof)
             achieved = flops / (ms * 1e-3) / 1e12

@@ -64,6 +64,52 @@ __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, cons
   }
 }
 
+// This thread's share of x.x, x.y, y.y for two rows.
+template <bool VEC>
+__device__ __forceinline__ void gram2_partial(const float* __restrict__ r0, const float* __restrict__ r1, int len,
+                                              float& xx, float& xy, float& yy) {
+  xx = xy = yy = 0.f;
+  if (VEC) {
+    const float4* a = reinterpret_cast<const float4*>(r0);
+    const float4* b = reinterpret_cast<const float4*>(r1);
+    const int n4 = len >> 2, bd = blockDim.x;
+    auto fma3 = [&](const float4& x, const float4& y) {
+      xx += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      xy += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      yy += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    };
+    int j = threadIdx.x;
+    for (; j + 3 * bd < n4; j += 4 * bd) {      // 8 loads in flight per thread
+      float4 x0 = a[j], y0 = b[j], x1 = a[j + bd], y1 = b[j + bd];
+      float4 x2 = a[j + 2 * bd], y2 = b[j + 2 * bd], x3 = a[j + 3 * bd], y3 = b[j + 3 * bd];
+      fma3(x0, y0);
+      fma3(x1, y1);
+      fma3(x2, y2);
+      fma3(x3, y3);
+    }
+    for (; j < n4; j += bd) {
+      float4 x = a[j], y = b[j];
+      fma3(x, y);
+    }
+  } else {
+    for (int j = threadIdx.x; j < len; j += blockDim.x) {
+      float x = r0[j], y = r1[j];
+      xx += x * x; xy += x * y; yy += y * y;
+    }
+  }
+}
+
+// This thread's share of u.a and u.b (short rows: the first layer's width).
+__device__ __forceinline__ void dot2_partial(const float* __restrict__ u, const float* __restrict__ a,
+                                             const float* __restrict__ b, int len, float& ua, float& ub) {
+  ua = ub = 0.f;
+  for (int j = threadIdx.x; j < len; j += blockDim.x) {
+    float x = u[j];
+    ua += x * a[j];
+    ub += x * b[j];
+  }
+}
+
 template <bool VEC_D, bool VEC_A>
 __global__ __launch_bounds__(256) void persample_gram_kernel(GramArgs a) {
   __shared__ double red[4][12];
@@ -126,6 +172,11 @@ struct GramAllArgs {
   int nlayers; int64_t n;
   float clip, gscale;
   double* norm2; float* rowc; const float* roww; float* rowc_w; float* norm_out;
+  // Implicit penalty row of layer 0 (zpre != NULL): act[0] holds only the fake and real rows [2n, K];
+  // the third row of example i would be v0_i = f_i * (u_i W1), u_i = delta[0] row 2n+i, and its inner
+  // products follow from the first layer's plain products zpre = x W1^T [2n, d] without forming it:
+  //   fake_i . v0_i = f_i * (u_i . zpre_i),  real_i . v0_i = f_i * (u_i . zpre_{n+i}),  v0_i . v0_i = f_i^2 q_i
+  const float* zpre; int64_t ldz; const float* gp_f; const double* gp_q; float* fc_out;
 };
 
 __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) {
@@ -139,7 +190,13 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
       const float* ac = a.act[l];
       if (a.vec_d[l]) gram3_partial<true>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
       else gram3_partial<false>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
-      if (a.vec_a[l]) gram3_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
+      const bool implicit = (l == 0 && a.zpre != nullptr);
+      if (implicit) {
+        if (a.vec_a[l]) gram2_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], a.K[l], g[6], g[7], g[9]);
+        else gram2_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], a.K[l], g[6], g[7], g[9]);
+        dot2_partial(dl + (2 * a.n + i) * a.ldd[l], a.zpre + i * a.ldz, a.zpre + (a.n + i) * a.ldz, a.d[l], g[8], g[10]);
+        g[11] = 0.f;
+      } else if (a.vec_a[l]) gram3_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
       else gram3_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
       double s[12];
 #pragma unroll
@@ -154,6 +211,12 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
         double t[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        if (implicit) {
+          const double f = (double)a.gp_f[i];
+          t[8] *= f;
+          t[10] *= f;
+          t[11] = f * f * a.gp_q[i];
+        }
         double v = t[0] * t[6] + t[3] * t[9] + t[5] * t[11] + 2.0 * (t[1] * t[7] + t[2] * t[8] + t[4] * t[10]);
         v += t[0] + 2.0 * t[1] + t[3];                     // bias: ||delta_0 + delta_1||^2
         total += v;
@@ -169,18 +232,21 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
         a.rowc[p * a.n + i] = c;
         if (a.rowc_w) a.rowc_w[p * a.n + i] = c * a.roww[p * a.n + i];
       }
+      if (a.fc_out) a.fc_out[i] = c * a.gp_f[i];
     }
   }
 }
 
 // delta / act: host arrays of nlayers device pointers (each [3n, d_l] / [3n, K_l]) with their
 // leading dimensions and widths.  Every layer counts its bias.
-extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
-                                      const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
-                                      float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
-                                      float* norm_out, void* stream) {
+static int persample_clip_all_impl(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
+                                   const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
+                                   float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
+                                   float* norm_out, const float* zpre, int64_t ldz, const float* gp_f,
+                                   const double* gp_q, float* fc_out, void* stream) {
   DPC_CHECK_ARG(nlayers >= 1 && nlayers <= DPC_MAX_LAYERS, "persample_clip_all: 1..8 layers");
   DPC_CHECK_ARG(delta && ldd && d && act && lda && K && norm2 && rowc && n > 0, "persample_clip_all: null pointer");
+  DPC_CHECK_ARG(!fc_out || gp_f, "persample_clip_all: fc_out needs gp_f");
   DPC_CHECK_ARG(clip > 0.f && gscale > 0.f, "persample_clip_all: clip bound and scale must be positive");
   DPC_CHECK_ARG(!rowc_w || roww, "persample_clip_all: row weights missing");
   GramAllArgs a;
@@ -192,10 +258,34 @@ extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, co
   }
   a.nlayers = nlayers; a.n = n; a.clip = clip; a.gscale = gscale; a.norm2 = norm2; a.rowc = rowc; a.roww = roww;
   a.rowc_w = rowc_w; a.norm_out = norm_out;
+  a.zpre = zpre; a.ldz = ldz; a.gp_f = gp_f; a.gp_q = gp_q; a.fc_out = fc_out;
   hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(256), 0,
                      (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
+}
+
+extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
+                                      const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
+                                      float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
+                                      float* norm_out, void* stream) {
+  return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
+                                 norm_out, nullptr, 0, nullptr, nullptr, nullptr, stream);
+}
+
+// The same with the penalty row of layer 0 left implicit (see GramAllArgs): act[0] is [2n, K[0]] (fake and
+// real rows), zpre [2n, d[0]] the first layer's plain products, gp_f / gp_q what dpc_gp_gram_rows
+// left behind.  fc_out[i] (nullable) = c_i * gp_f[i], the per-row scale of the penalty's Gram-form
+// weight gradient P = u^T diag(fc) u.
+extern "C" int dpc_persample_clip_all_gram(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
+                                           const float* const* act, const int64_t* lda, const int* K, int64_t n,
+                                           float clip, float gscale, double* norm2, float* rowc, const float* roww,
+                                           float* rowc_w, float* norm_out, const float* zpre, int64_t ldz,
+                                           const float* gp_f, const double* gp_q, float* fc_out, void* stream) {
+  DPC_CHECK_ARG(zpre && gp_f && gp_q, "persample_clip_all_gram: null pointer");
+  DPC_CHECK_ARG(nlayers >= 1 && d && ldz >= d[0], "persample_clip_all_gram: ldz < d[0]");
+  return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
+                                 norm_out, zpre, ldz, gp_f, gp_q, fc_out, stream);
 }
 
 // c_i = min(1, clip / (gscale * sqrt(norm2[i]))); rowc[p*n + i] = c_i for the three rows of example i

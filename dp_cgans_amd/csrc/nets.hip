@@ -101,19 +101,31 @@ __global__ __launch_bounds__(256) void colreduce_finish_kernel(const double* __r
                                                                int kind, double count, float eps, float momentum,
                                                                float* out0, float* out1, float* run_mean,
                                                                float* run_var, int accumulate) {
-  int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+  // block = 64 columns x 4 row lanes: lane rl adds chunks rl, rl+4, ... (all loads of a lane independent,
+  // 8 in flight), then the four lane sums are added in a fixed order - the walk over up to 64 chunks by
+  // one thread per column was a chain of dependent L2 round trips (8 us per launch at T1M)
+  __shared__ double red[2][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + c;
   double s0 = 0.0, s1 = 0.0;
-  if (nout == 2) {
+  if (f < F) {
+    if (nout == 2) {
+#pragma unroll 4
+      for (int r = rl; r < R; r += 4) {
+        s0 += part[((int64_t)r * 2 + 0) * F + f];
+        s1 += part[((int64_t)r * 2 + 1) * F + f];
+      }
+    } else {
 #pragma unroll 8
-    for (int r = 0; r < R; ++r) {
-      s0 += part[((int64_t)r * 2 + 0) * F + f];
-      s1 += part[((int64_t)r * 2 + 1) * F + f];
+      for (int r = rl; r < R; r += 4) s0 += part[(int64_t)r * F + f];
     }
-  } else {
-#pragma unroll 8
-    for (int r = 0; r < R; ++r) s0 += part[(int64_t)r * F + f];
   }
+  red[0][rl][c] = s0;
+  red[1][rl][c] = s1;
+  __syncthreads();
+  if (rl != 0 || f >= F) return;
+  s0 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+  s1 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   if (kind == 0) {
     double mean = s0 / count;
     double var = s1 / count - mean * mean;
@@ -138,7 +150,7 @@ extern "C" int dpc_colreduce_finish(const double* part, int R, int nout, int F, 
   DPC_CHECK_ARG(R >= 1 && (nout == 1 || nout == 2) && F > 0 && kind >= 0 && kind <= 2, "colreduce_finish: bad argument");
   DPC_CHECK_ARG(nout == 1 || out1, "colreduce_finish: second output missing");
   DPC_CHECK_ARG(kind != 0 || (nout == 2 && count > 0.0), "colreduce_finish: statistics need two sums and a count");
-  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 64)), dim3(256), 0, (hipStream_t)stream, part,
                      R, nout, F, kind, count, eps, momentum, out0, out1, run_mean, run_var, accumulate);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
@@ -374,6 +386,148 @@ extern "C" int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef,
   else
     hipLaunchKernelGGL(gp_norm_kernel<false>, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, g0,
                        ld, n, K0, coef, pen_rows, nrm_out);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Discriminator update, first hidden layer over the stacked batch [fake | real | interpolates]
+// without ever forming the interpolates (dp_cgan.py:47-53): the layer is linear before its
+// activation, so with one alpha per pac group (= per row of the [n, K0] view)
+//     (a*real + (1-a)*fake) W^T = a * (real W^T) + (1-a) * (fake W^T).
+// zpre [2n, d] holds the plain products of the fake rows (0..n-1) and the real rows (n..2n-1);
+// this pass writes, for all 3n stacked rows p*n + r, the Linear + LeakyReLU + Dropout(0.5) output
+// H and the slope S = (pre > 0 ? 1 : leak) * keep * 2 exactly as the GEMM's fused epilogue does
+// (keep bit: keep[row, col] or Philox draw row*d + col of site_keep; alpha: alpha_inj[r] or draw r
+// of site_alpha - the same index maps as dpc_gemm_f32 / dpc_interpolate).
+// ---------------------------------------------------------------------------------------------
+struct FirstActArgs {
+  const float* zpre; int64_t ldz; const float* bias; int64_t n; int d;
+  const float* alpha_inj; const uint8_t* keep; int64_t ld_keep;
+  const uint64_t* rng; uint32_t site_alpha, site_keep; float leak;
+  float* H; int64_t ldh; float* S; int64_t lds; float* alpha_out;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
+  constexpr int W = VEC ? 4 : 1;
+  const int per_row = a.d / W;
+  const int64_t total = a.n * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row;
+    const int j = (int)(i - r * per_row) * W;
+    const float al = a.alpha_inj ? a.alpha_inj[r] : dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site_alpha, (uint64_t)r));
+    if (a.alpha_out && j == 0) a.alpha_out[r] = al;
+    float zf[W], zr[W], b[W];
+    if constexpr (VEC) {
+      const float4 f4 = *reinterpret_cast<const float4*>(a.zpre + r * a.ldz + j);
+      const float4 r4 = *reinterpret_cast<const float4*>(a.zpre + (a.n + r) * a.ldz + j);
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + j);
+      zf[0] = f4.x; zf[1] = f4.y; zf[2] = f4.z; zf[3] = f4.w;
+      zr[0] = r4.x; zr[1] = r4.y; zr[2] = r4.z; zr[3] = r4.w;
+      b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+    } else {
+      zf[0] = a.zpre[r * a.ldz + j];
+      zr[0] = a.zpre[(a.n + r) * a.ldz + j];
+      b[0] = a.bias[j];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int64_t row = (int64_t)p * a.n + r;
+      uint32_t bits[W];
+      if (a.keep) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) bits[e] = a.keep[row * a.ld_keep + j + e] ? 0x80000000u : 0u;
+      } else if constexpr (VEC) {
+        // d % 4 == 0: the four draws row*d + j .. + 3 are one Philox block
+        DpcPhilox4 ph = dpc_philox(a.rng[0], a.rng[1], a.site_keep, ((uint64_t)row * a.d + j) >> 2);
+        bits[0] = ph.v[0]; bits[1] = ph.v[1]; bits[2] = ph.v[2]; bits[3] = ph.v[3];
+      } else {
+        bits[0] = dpc_draw_u32(a.rng, a.site_keep, (uint64_t)row * a.d + j);
+      }
+      float h[W], s[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const float pre = (p == 0 ? zf[e] : (p == 1 ? zr[e] : al * zr[e] + (1.f - al) * zf[e])) + b[e];
+        s[e] = (pre > 0.f ? 1.f : a.leak) * ((bits[e] >> 31) ? 2.f : 0.f);
+        h[e] = pre * s[e];
+      }
+      if constexpr (VEC) {
+        *reinterpret_cast<float4*>(a.H + row * a.ldh + j) = make_float4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<float4*>(a.S + row * a.lds + j) = make_float4(s[0], s[1], s[2], s[3]);
+      } else {
+        a.H[row * a.ldh + j] = h[0];
+        a.S[row * a.lds + j] = s[0];
+      }
+    }
+  }
+}
+
+extern "C" int dpc_disc_first_layer_act(const float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
+                                        const float* alpha_inj, const uint8_t* keep, int64_t ld_keep,
+                                        const uint64_t* rng, uint32_t site_alpha, uint32_t site_keep, float leak,
+                                        float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, void* stream) {
+  DPC_CHECK_ARG(zpre && bias && H && S && n > 0 && d > 0, "disc_first_layer_act: bad argument");
+  DPC_CHECK_ARG(ldz >= d && ldh >= d && lds >= d, "disc_first_layer_act: leading dimension < d");
+  DPC_CHECK_ARG((alpha_inj && keep) || rng, "disc_first_layer_act: no random source");
+  DPC_CHECK_ARG(!keep || ld_keep >= d, "disc_first_layer_act: ld_keep < d");
+  FirstActArgs a;
+  a.zpre = zpre; a.ldz = ldz; a.bias = bias; a.n = n; a.d = d; a.alpha_inj = alpha_inj; a.keep = keep; a.ld_keep = ld_keep;
+  a.rng = rng; a.site_alpha = site_alpha; a.site_keep = site_keep; a.leak = leak; a.H = H; a.ldh = ldh; a.S = S; a.lds = lds;
+  a.alpha_out = alpha_out;
+  const bool vec = (d % 4 == 0) && (ldz % 4 == 0) && (ldh % 4 == 0) && (lds % 4 == 0) &&
+                   ((((uintptr_t)zpre | (uintptr_t)bias | (uintptr_t)H | (uintptr_t)S) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(disc_first_act_kernel<true>, dim3(dpc_grid(n * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(disc_first_act_kernel<false>, dim3(dpc_grid(n * d, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient penalty through the first layer's Gram matrix G = W1 W1^T (d x d) instead of the K0-wide
+// products (calc_gradient_penalty, dp_cgan.py:55-62, analytic form of SURVEY a4).  With u = the
+// penalty rows of the first layer's backward delta and T = u G:
+//     ||grad_xhat D||^2 = ||u W1||^2 = u G u^T = rowsum(T * u)                       (g0 is never formed)
+//     v0 = f * (u W1),  f = coef * (nrm - 1) / nrm   =>   v1 = (v0 W1^T) * S1 = f * T * S1
+// One wave per row.  Outputs: pen_rows[r] = (nrm-1)^2, f_out[r] = f, q_out[r] = ||g0||^2 (fp64),
+// v1[r,:] (the penalty rows of the first hidden layer's v-chain).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_gram_rows_kernel(const float* __restrict__ T, int64_t ldt,
+                                                           const float* __restrict__ u, int64_t ldu,
+                                                           const float* __restrict__ slope, int64_t lds, int64_t n,
+                                                           int d, float coef, double* __restrict__ pen_rows,
+                                                           float* __restrict__ f_out, double* __restrict__ q_out,
+                                                           float* __restrict__ nrm_out, float* __restrict__ v1,
+                                                           int64_t ldv) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+    double acc = 0.0;
+    for (int j = lane; j < d; j += 64) acc += (double)T[r * ldt + j] * (double)u[r * ldu + j];
+    double q = dpc_wave_sum(acc);
+    if (q < 0.0) q = 0.0;
+    const float nrm = (float)sqrt(q);
+    const float f = nrm > 0.f ? coef * (nrm - 1.f) / nrm : 0.f;
+    for (int j = lane; j < d; j += 64) v1[r * ldv + j] = f * T[r * ldt + j] * slope[r * lds + j];
+    if (lane == 0) {
+      pen_rows[r] = (double)(nrm - 1.f) * (double)(nrm - 1.f);
+      f_out[r] = f;
+      if (q_out) q_out[r] = q;
+      if (nrm_out) nrm_out[r] = nrm;
+    }
+  }
+}
+
+extern "C" int dpc_gp_gram_rows(const float* T, int64_t ldt, const float* u, int64_t ldu, const float* slope,
+                                int64_t lds, int64_t n, int d, float coef, double* pen_rows, float* f_out,
+                                double* q_out, float* nrm_out, float* v1, int64_t ldv, void* stream) {
+  DPC_CHECK_ARG(T && u && slope && pen_rows && f_out && v1 && n > 0 && d > 0, "gp_gram_rows: bad argument");
+  DPC_CHECK_ARG(ldt >= d && ldu >= d && lds >= d && ldv >= d, "gp_gram_rows: leading dimension < d");
+  int64_t blocks = dpc_cdiv(n, 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gp_gram_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, ldt, u, ldu, slope,
+                     lds, n, d, coef, pen_rows, f_out, q_out, nrm_out, v1, ldv);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

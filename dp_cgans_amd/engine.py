@@ -16,6 +16,9 @@ Memory layout (all fp32, row-major, resident in HBM for the whole fit):
                                   groups, 2n..3n-1 interpolates (later overwritten by the penalty's
                                   v-chain so that one GEMM per layer yields loss + penalty weight grads)
   H_i, S_i, D_i [3n, d_i]         activations, slopes (mask*2*{1,.2}), backward deltas per hidden layer
+  Zp [2n, d_0], G1 [d_0, d_0]     Gram-form penalty (gp_gram): first-layer plain products x W1^T of the fake
+                                  and real rows, and W1 W1^T; the interpolates and the K0-wide penalty
+                                  gradient are then never formed (third block of Xd unused)
 """
 import math
 
@@ -134,10 +137,12 @@ class GenContext(object):
 
 
 class StepEngine(object):
+    GP_GRAM = None      # test hook: True / False overrides the automatic choice of the penalty's form
+
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
                  private=False, seed=0, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
-                 weight_clip=None):
+                 weight_clip=None, gp_gram=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
         self.span_info_np = np.asarray(span_info, dtype=np.int32).reshape(-1, 3)
@@ -254,6 +259,20 @@ class StepEngine(object):
         # both backward passes (penalty, loss_d) fire every hook except the last bias's, which only
         # loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
         self.hook_fires = torch.tensor([2.0] * (len(self.disc.keys) - 1) + [1.0], **f32)
+        # Gradient penalty through the first layer's Gram matrix W1 W1^T (see _d_back): on by default
+        # when the batch of pac groups is at least half as tall as the first hidden layer is wide
+        # (the d0 x d0 x K0 Gram product then costs less than the three n x d0 x K0 products it replaces)
+        if gp_gram is None:
+            gp_gram = StepEngine.GP_GRAM
+        self.gp_gram = bool(gp_gram) if gp_gram is not None else (2 * n >= self.ddim[0])
+        d0 = self.ddim[0]
+        self.Zp = torch.zeros(2 * n, d0, **f32)        # first layer's plain products of the fake and real rows
+        self.G1 = torch.zeros(d0, d0, **f32)           # W1 W1^T
+        self.Tq = torch.zeros(n, d0, **f32)            # u G1
+        self.P1 = torch.zeros(d0, d0, **f32)           # u^T diag(f c) u
+        self.gp_f = torch.zeros(n, **f32)
+        self.gp_fc = torch.zeros(n, **f32)
+        self.gp_q = torch.zeros(n, device=d, dtype=torch.float64)
         self.norm2 = torch.zeros(n, device=d, dtype=torch.float64)      # DP-SGD: per-example squared gradient norms
         self.norms = torch.zeros(n, **f32)
         self.rowc = torch.ones(3 * n, **f32)                              # clip factor of each stacked row
@@ -491,6 +510,26 @@ class StepEngine(object):
             ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), y, rowscale=rowscale,
                              slope=self.S[M - 1][rs], delta=self.Dl[M - 1][rs])
 
+    def _disc_forward_stacked(self, inj):
+        """Discriminator forward of the discriminator update over the 3n stacked rows [fake | real |
+        interpolates] (dp_cgan.py:629-630, :47-53) WITHOUT forming the interpolates: the first Linear's
+        products are taken for the fake and real rows only, and those of xhat = a*real + (1-a)*fake follow
+        by linearity inside the activation pass; the other layers run over all 3n rows as usual."""
+        d, M, n = self.disc, self.M, self.n
+        ops.gemm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True)
+        keeps = inj.get('keep')
+        ops.disc_first_layer_act(self.Zp, d.P('seq.0.bias'), n, self.H[0], self.S[0], alpha_inj=inj.get('alpha'),
+                                 keep=keeps[0] if keeps else None, rng=self.rng, site_alpha=ops.SITE_ALPHA + self._so,
+                                 site_keep=ops.SITE_DROP0 + self._so, leak=LEAK)
+        x = self.H[0]
+        for i in range(1, M):
+            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
+                     epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i], keep=keeps[i] if keeps else None,
+                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
+            x = self.H[i]
+        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), self.y,
+                         rowscale=self.rowscale_d, slope=self.S[M - 1], delta=self.Dl[M - 1])
+
     def score_real_rows(self, inj=None):
         """Discriminator output on a freshly sampled batch of real rows with their cond vectors
         (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
@@ -581,26 +620,43 @@ class StepEngine(object):
         n, B, M, d = self.n, self.B, self.M, self.disc
         self._last = self.cd
         self._join()
-        ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
-                        rng=self.rng, site=ops.SITE_ALPHA + self._so)
-        self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
+        W1 = d.P('seq.0.weight')
+        gp_rows = slice(2 * n, 3 * n)
+        gram = self.gp_gram
+        coef = 2.0 * GP_LAMBDA / self.gn
+        if gram:
+            # Gram-form penalty.  With G1 = W1 W1^T (d0 x d0) and u = the penalty rows of Dl[0]:
+            #   ||grad_xhat D||^2 = ||u W1||^2 = rowsum((u G1) * u)       v1 = f * (u G1) * S_1
+            #   penalty part of dW1 = u^T v0 = (u^T diag(f) u) W1
+            # so neither xhat, g0 = u W1 nor v0 (each [n, K0]) is formed, and the K0-wide products
+            # shrink from 3n to 2n rows (forward, weight gradient) or disappear (g0, v1).
+            with self._fork(0):
+                ops.gemm(W1, W1, self.G1, trans_b=True)        # beside the forward
+            self._disc_forward_stacked(inj)
+        else:
+            ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
+                            rng=self.rng, site=ops.SITE_ALPHA + self._so)
+            self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
         self._loss_dirty[0] = True
         if self._early_hook is not None:      # see train_step
             self._early_hook()
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
         self._disc_chain_down(3 * n, self.rowscale_d)
-        W1 = d.P('seq.0.weight')
-        gp_rows = slice(2 * n, 3 * n)
-        ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
-        ops.gp_norm(self.Xd3[gp_rows], 2.0 * GP_LAMBDA / self.gn, self.pen_rows)    # -> v0 in place
         # penalty v-chain first, so that every layer's (delta, input) pair exists before the DP clip
         # factors: v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
-        prev = self.Xd3
-        for i in range(M):
-            ops.gemm(prev[gp_rows], d.P('seq.%d.weight' % (3 * i)), self.H[i][gp_rows], trans_b=True, epi=ops.EPI_MUL,
-                     aux_in=self.S[i][gp_rows])
-            prev = self.H[i]
-        kscale, w_last, w_bias = None, self.rowscale_d, None
+        if gram:
+            self._join()
+            ops.gemm(self.Dl[0][gp_rows], self.G1, self.Tq)
+            ops.gp_gram_rows(self.Tq, self.Dl[0][gp_rows], self.S[0][gp_rows], coef, self.pen_rows, self.gp_f,
+                             self.H[0][gp_rows], q_out=self.gp_q)
+        else:
+            ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
+            ops.gp_norm(self.Xd3[gp_rows], coef, self.pen_rows)                     # -> v0 in place
+            ops.gemm(self.Xd3[gp_rows], W1, self.H[0][gp_rows], trans_b=True, epi=ops.EPI_MUL, aux_in=self.S[0][gp_rows])
+        for i in range(1, M):
+            ops.gemm(self.H[i - 1][gp_rows], d.P('seq.%d.weight' % (3 * i)), self.H[i][gp_rows], trans_b=True,
+                     epi=ops.EPI_MUL, aux_in=self.S[i][gp_rows])
+        kscale, w_last, w_bias, pen_scale = None, self.rowscale_d, None, self.gp_f
         if self.dp_mode == 'dpsgd':
             # per-example gradient norms (ghost norm over the 3 rows of each pac group) of every layer and
             # the clip factors, one launch
@@ -609,8 +665,14 @@ class StepEngine(object):
                 layers.append((self.Dl[i], prev))
                 prev = self.H[i]
             layers.append((self.rowscale_d.view(-1, 1), prev))
-            ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc, roww=self.rowscale_d,
-                                   rowc_w=self.rowc_w, norm_out=self.norms)
+            if gram:
+                ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
+                                       roww=self.rowscale_d, rowc_w=self.rowc_w, norm_out=self.norms, zpre=self.Zp,
+                                       gp_f=self.gp_f, gp_q=self.gp_q, fc_out=self.gp_fc)
+                pen_scale = self.gp_fc
+            else:
+                ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
+                                       roww=self.rowscale_d, rowc_w=self.rowc_w, norm_out=self.norms)
             kscale, w_last, w_bias = self.rowc, self.rowc_w, self.rowc[0:2 * n]
         # weight gradients: the first layer's product (K0 wide) on the main stream, everything else beside it
         with self._fork(0) as part:
@@ -623,8 +685,16 @@ class StepEngine(object):
             self._colsum(self.H[M - 1], d.G('seq.%d.weight' % (3 * M)), w=w_last, part=part)
             self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=w_last[0:2 * n], part=part)
             self._colsum(self.Dl[0][0:2 * n], d.G('seq.0.bias').view(1, -1), w=w_bias, part=part)
-        # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
-        ops.gemm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
+        if gram:
+            # penalty part (u^T diag(f c) u) W1 fills the gradient, the fake and real rows' product adds to it
+            u = self.Dl[0][gp_rows]
+            ops.gemm(u, u, self.P1, trans_a=True, kscale=pen_scale)
+            ops.gemm(self.P1, W1, d.G('seq.0.weight'))
+            ops.gemm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
+                     kscale=kscale[0:2 * n] if kscale is not None else None)
+        else:
+            # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
+            ops.gemm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
         self._join()
         if update:
             self._disc_update(inj)

@@ -271,6 +271,30 @@ def gp_norm(g0, coef, pen_rows, nrm_out=None):
     lib().call('dpc_gp_norm', _p(g0), _ld(g0), g0.shape[0], g0.shape[1], coef, _p(pen_rows), _p(nrm_out), _stream())
 
 
+def disc_first_layer_act(zpre, bias, n, H, S, alpha_inj=None, keep=None, rng=None, site_alpha=SITE_ALPHA,
+                         site_keep=SITE_DROP0, leak=0.2, alpha_out=None):
+    """H, S [3n, d] of the stacked rows [fake | real | interpolates] from zpre [2n, d] = x W1^T."""
+    _chk(keep, torch.uint8, 'keep')
+    d = zpre.shape[1]
+    if zpre.shape[0] != 2 * n or H.shape[0] != 3 * n or S.shape[0] != 3 * n or H.shape[1] != d or S.shape[1] != d:
+        raise ValueError('disc_first_layer_act: zpre needs 2n rows, H and S 3n rows of the same width')
+    if keep is not None and (keep.shape[0] != 3 * n or keep.shape[1] != d):
+        raise ValueError('disc_first_layer_act: keep must be [3n, d]')
+    lib().call('dpc_disc_first_layer_act', _p(zpre), _ld(zpre), _p(bias), n, d, _p(alpha_inj), _p(keep),
+               _ld(keep) if keep is not None else 0, _p(rng), site_alpha, site_keep, leak, _p(H), _ld(H), _p(S), _ld(S),
+               _p(alpha_out), _stream())
+
+
+def gp_gram_rows(T, u, slope, coef, pen_rows, f_out, v1, q_out=None, nrm_out=None):
+    _chk(pen_rows, torch.float64, 'pen_rows')
+    _chk(q_out, torch.float64, 'q_out')
+    n, d = T.shape
+    if u.shape != T.shape or slope.shape != T.shape or v1.shape != T.shape:
+        raise ValueError('gp_gram_rows: T, u, slope, v1 must have one shape')
+    lib().call('dpc_gp_gram_rows', _p(T), _ld(T), _p(u), _ld(u), _p(slope), _ld(slope), n, d, coef, _p(pen_rows),
+               _p(f_out), _p(q_out), _p(nrm_out), _p(v1), _ld(v1), _stream())
+
+
 def sum_f64(v, scale, out, accumulate=False):
     lib().call('dpc_sum_f64', _p(v), v.numel(), float(scale), _p(out), int(accumulate), _stream())
 
@@ -313,22 +337,33 @@ def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK, t_add=1):
                site, _stream())
 
 
-def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=None, norm_out=None):
-    """layers: [(delta [3n,d], act [3n,K])]; all Gram contractions and the clip factors in one launch."""
+def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=None, norm_out=None, zpre=None,
+                       gp_f=None, gp_q=None, fc_out=None):
+    """layers: [(delta [3n,d], act [3n,K])]; all Gram contractions and the clip factors in one launch.
+    With ``zpre`` the penalty row of layer 0's act is implicit (act[0] needs only its first 2n rows):
+    see dpc_persample_clip_all_gram."""
     _chk(norm2, torch.float64, 'norm2')
+    _chk(gp_q, torch.float64, 'gp_q')
     L = len(layers)
-    for dl, ac in layers:
+    for l, (dl, ac) in enumerate(layers):
         _chk(dl, torch.float32, 'delta')
         _chk(ac, torch.float32, 'act')
-        if dl.shape[0] != 3 * n or ac.shape[0] != 3 * n:
+        need = 2 * n if (l == 0 and zpre is not None) else 3 * n
+        if dl.shape[0] != 3 * n or ac.shape[0] < need:
             raise ValueError('persample_clip_all: delta/act need 3n rows')
     P = ctypes.c_void_p * L
     I64 = ctypes.c_int64 * L
     I32 = ctypes.c_int * L
-    lib().call('dpc_persample_clip_all', L, P(*[dl.data_ptr() for dl, _ in layers]), I64(*[_ld(dl) for dl, _ in layers]),
-               I32(*[dl.shape[1] for dl, _ in layers]), P(*[ac.data_ptr() for _, ac in layers]),
-               I64(*[_ld(ac) for _, ac in layers]), I32(*[ac.shape[1] for _, ac in layers]), n, float(clip),
-               float(gscale), _p(norm2), _p(rowc), _p(roww), _p(rowc_w), _p(norm_out), _stream())
+    args = [L, P(*[dl.data_ptr() for dl, _ in layers]), I64(*[_ld(dl) for dl, _ in layers]),
+            I32(*[dl.shape[1] for dl, _ in layers]), P(*[ac.data_ptr() for _, ac in layers]),
+            I64(*[_ld(ac) for _, ac in layers]), I32(*[ac.shape[1] for _, ac in layers]), n, float(clip),
+            float(gscale), _p(norm2), _p(rowc), _p(roww), _p(rowc_w), _p(norm_out)]
+    if zpre is None:
+        lib().call('dpc_persample_clip_all', *args, _stream())
+    else:
+        if zpre.shape[0] != 2 * n or zpre.shape[1] != layers[0][0].shape[1]:
+            raise ValueError('persample_clip_all: zpre must be [2n, d0]')
+        lib().call('dpc_persample_clip_all_gram', *args, _p(zpre), _ld(zpre), _p(gp_f), _p(gp_q), _p(fc_out), _stream())
 
 
 def condvec_original(table, cond_st, dims, matrix_st, cond, rows_inj=None, cols_inj=None, rng=None, site=SITE_CONDVEC):

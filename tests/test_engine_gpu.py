@@ -11,6 +11,16 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
+@pytest.fixture(autouse=True, params=['penalty-direct', 'penalty-gram'])
+def penalty_form(request):
+    """Every test of this file runs with both forms of the discriminator update's first layer: the
+    direct one (interpolates, g0 = u W1 and v0 formed) and the Gram one (W1 W1^T; engine._d_back)."""
+    from dp_cgans_amd.engine import StepEngine
+    StepEngine.GP_GRAM = request.param == 'penalty-gram'
+    yield request.param
+    StepEngine.GP_GRAM = None
+
+
 def close(a, b, rtol=RTOL, what='', scale=None):
     a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)

@@ -484,6 +484,115 @@ def test_persample_gram_and_clip_factors(ops, n, d, K):
     assert (want_c < 1).any() and (want_c == 1).any()
 
 
+@pytest.mark.parametrize('n,d,K0', [(50, 256, 940), (9, 21, 37), (128, 64, 488)])
+def test_first_layer_act_equals_interpolate_then_linear(ops, n, d, K0):
+    """dpc_disc_first_layer_act on the plain products of the fake and real rows == the direct route
+    (dpc_interpolate, then Linear + LeakyReLU + Dropout over all 3n rows through the GEMM epilogue),
+    with injected alpha / keep bits and with Philox draws (same index maps)."""
+    g = torch.Generator().manual_seed(n + d)
+    d_ = dev()
+    X = torch.zeros(3 * n, K0, device=d_)
+    X[0:2 * n] = torch.randn(2 * n, K0, generator=g).to(d_)
+    W = (torch.randn(d, K0, generator=g) / K0 ** 0.5).to(d_)
+    b = (torch.randn(d, generator=g) * 0.1).to(d_)
+    alpha = torch.rand(n, generator=g).to(d_)
+    keep = (torch.rand(3 * n, d, generator=g) > 0.5).to(torch.uint8).to(d_)
+    rng = ops.new_rng(77, d_)
+    for inj in (True, False):
+        kw = dict(keep=keep) if inj else {}
+        ops.interpolate(X[n:2 * n], X[0:n], X[2 * n:], n, K0, alpha_inj=alpha if inj else None, rng=rng, site=ops.SITE_ALPHA)
+        H_ref, S_ref = torch.empty(3 * n, d, device=d_), torch.empty(3 * n, d, device=d_)
+        ops.gemm(X, W, H_ref, trans_b=True, bias=b, epi=ops.EPI_LEAKY_DROPOUT, aux_out=S_ref, rng=rng, site=ops.SITE_DROP0,
+                 leak=0.2, **kw)
+        Zp = torch.empty(2 * n, d, device=d_)
+        ops.gemm(X[0:2 * n], W, Zp, trans_b=True)
+        H, S = torch.full((3 * n, d), float('nan'), device=d_), torch.full((3 * n, d), float('nan'), device=d_)
+        aout = torch.empty(n, device=d_)
+        ops.disc_first_layer_act(Zp, b, n, H, S, alpha_inj=alpha if inj else None, rng=rng, site_alpha=ops.SITE_ALPHA,
+                                 site_keep=ops.SITE_DROP0, leak=0.2, alpha_out=aout, **kw)
+        if inj:
+            assert torch.equal(aout, alpha)
+        # the fake and real rows go through identical arithmetic up to the GEMM's summation order
+        # (split-K or not): pre-activations within rounding of zero may pick the other slope
+        pre = (X.double() @ W.double().t() + b.double()).cpu()
+        sure = (pre.abs() > 1e-5 * pre.abs().max())
+        assert torch.equal(S.cpu()[sure], S_ref.cpu()[sure])
+        assert sure.float().mean() > 0.99
+        close(H.cpu()[sure], H_ref.cpu()[sure], what='first layer H (inj %s)' % inj)
+        keep_bits = (S.cpu() != 0)
+        if inj:
+            assert torch.equal(keep_bits, keep.cpu().bool())
+        else:
+            kb = torch.empty(3 * n, d, dtype=torch.uint8, device=d_)
+            ops.fill(kb, ops.FILL_KEEP, rng, ops.SITE_DROP0)
+            assert torch.equal(keep_bits, kb.cpu().bool())
+
+
+@pytest.mark.parametrize('n,d,K0', [(50, 256, 940), (7, 21, 37)])
+def test_gp_gram_rows_equals_the_direct_penalty(ops, n, d, K0):
+    """rowsum((u G) * u) with G = W W^T == ||u W||^2, and v1 = f (u G) S == ((f u W) W^T) S (dpc_gp_norm route)."""
+    g = torch.Generator().manual_seed(n * d)
+    d_ = dev()
+    W = (torch.randn(d, K0, generator=g) / K0 ** 0.5)
+    u = torch.randn(n, d, generator=g) * 0.7
+    S = ((torch.rand(n, d, generator=g) > 0.5).float() * 2) * torch.where(torch.rand(n, d, generator=g) > 0.5, 1.0, 0.2)
+    coef = 2.0 * 10.0 / n
+    g0 = u.double() @ W.double()
+    nrm = g0.norm(dim=1)
+    f = coef * (nrm - 1) / nrm
+    v1_ref = ((f[:, None] * g0) @ W.double().t()) * S.double()
+    G = torch.empty(d, d, device=d_)
+    ops.gemm(W.to(d_), W.to(d_), G, trans_b=True)
+    T = torch.empty(n, d, device=d_)
+    ops.gemm(u.to(d_), G, T)
+    pen = torch.empty(n, dtype=torch.float64, device=d_)
+    q = torch.empty(n, dtype=torch.float64, device=d_)
+    fo, no = torch.empty(n, device=d_), torch.empty(n, device=d_)
+    v1 = torch.empty(n, d, device=d_)
+    ops.gp_gram_rows(T, u.to(d_), S.to(d_), coef, pen, fo, v1, q_out=q, nrm_out=no)
+    close(no, nrm, what='gradient norms')
+    close(q, nrm ** 2, what='squared norms')
+    close(pen, (nrm - 1) ** 2, what='penalty rows')
+    close(fo, f, what='f')
+    close(v1, v1_ref, what='v1')
+
+
+@pytest.mark.parametrize('n,dims', [(7, [(5, 13), (3, 5), (1, 3)]), (40, [(32, 940), (16, 32), (1, 16)]), (33, [(256, 4888), (1, 256)])])
+def test_persample_clip_all_with_implicit_penalty_row(ops, n, dims):
+    """dpc_persample_clip_all_gram == dpc_persample_clip_all on the same layers with the penalty row of
+    layer 0's input materialised as v0 = f * (u W1)."""
+    g = torch.Generator().manual_seed(n)
+    d_ = dev()
+    d0, K0 = dims[0]
+    W = torch.randn(d0, K0, generator=g) / K0 ** 0.5
+    X = torch.randn(2 * n, K0, generator=g)
+    deltas = [torch.randn(3 * n, d, generator=g) * 0.1 for d, _ in dims]
+    acts = [None] + [torch.randn(3 * n, K, generator=g) for _, K in dims[1:]]
+    u = deltas[0][2 * n:]
+    f = torch.randn(n, generator=g)
+    g0 = u.double() @ W.double()
+    q = (g0 ** 2).sum(1)
+    full = torch.cat([X, (f.double()[:, None] * g0).float()], 0)
+    zpre = (X.double() @ W.double().t()).float()
+    roww = torch.randn(3 * n, generator=g).to(d_)
+
+    def run(act0, **kw):
+        layers = [(deltas[0].to(d_), act0.to(d_))] + [(dl.to(d_), ac.to(d_)) for dl, ac in zip(deltas[1:], acts[1:])]
+        norm2 = torch.empty(n, dtype=torch.float64, device=d_)
+        rowc, rowcw, nrm = torch.empty(3 * n, device=d_), torch.empty(3 * n, device=d_), torch.empty(n, device=d_)
+        ops.persample_clip_all(layers, n, kw.pop('clip'), 3.0, norm2, rowc, roww=roww, rowc_w=rowcw, norm_out=nrm, **kw)
+        return norm2, rowc, rowcw, nrm
+    ref = run(full, clip=1e30)
+    clip = float(ref[3].median())
+    ref = run(full, clip=clip)
+    fc = torch.empty(n, device=d_)
+    got = run(X, clip=clip, zpre=zpre.to(d_), gp_f=f.to(d_), gp_q=q.to(d_), fc_out=fc)
+    for a, b, what in zip(got, ref, ('norm2', 'rowc', 'rowc_w', 'norms')):
+        close(a, b, what=what)
+    close(fc, got[1][0:n].cpu() * f, what='fc')
+    assert float(got[1].min()) < 1.0 and float(got[1].max()) == 1.0
+
+
 def test_gemm_kscale_is_the_clip_scale_sum(ops):
     g = torch.Generator().manual_seed(21)
     for rows, d, K in [(150, 32, 940), (3072, 256, 611), (96, 24, 48)]:
