@@ -42,7 +42,19 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int a_vec, b_vec;
   const float* kscale;   // optional: A(m,k) *= kscale[k] (fused clip-scale-sum; m-contiguous A only)
+  // optional row gather added before the epilogue: C[m,n] += gat[gidx[m][0]][n] + gat[gidx[m][1]][n]
+  // (negative ids skipped).  It stands for the columns of A that hold a one-/two-hot conditional
+  // vector: their product with W^T is the sum of the hot columns of W, i.e. rows of gat = W^T slice.
+  const float* gat; int64_t ldg; const int32_t* gidx;
 };
+
+__device__ __forceinline__ float gemm_gather2(const GemmArgs& g, int row, int col) {
+  const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
+  float v = 0.f;
+  if (i0 >= 0) v += g.gat[(int64_t)i0 * g.ldg + col];
+  if (i1 >= 0) v += g.gat[(int64_t)i1 * g.ldg + col];
+  return v;
+}
 
 constexpr int BK = 32;
 
@@ -258,6 +270,43 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     __syncthreads();
   }
 
+  // Row gather (see GemmArgs::gat): the block stages its BM x BN share of gat[gidx[m][0]] + gat[gidx[m][1]]
+  // in LDS with 16-byte loads along the rows of gat (the MFMA output layout holds one column per lane:
+  // gathering from there would be 2 x 16 scalar loads per lane and tile, more than a short K loop issues).
+  const bool gather = (g.gat != nullptr) && !atomic;
+  if (gather) {
+    static_assert(BM * BN <= 2 * SA::SIZE + 2 * SB::SIZE, "gather image must fit the operand buffers");
+    constexpr int V = BN / 4;
+    const bool vec = ((g.ldg & 3) == 0) && (((uintptr_t)g.gat & 15) == 0) && (n0 + BN <= g.N);
+    for (int idx = threadIdx.x; idx < BM * V; idx += 256) {
+      const int r = idx / V, c4 = (idx - r * V) * 4;
+      const int row = m0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < g.M) {
+        const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
+        if (vec) {
+          if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
+          if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
+        } else {
+          float e4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = n0 + c4 + e;
+            float x = 0.f;
+            if (col < g.N) {
+              if (i0 >= 0) x += g.gat[(int64_t)i0 * g.ldg + col];
+              if (i1 >= 0) x += g.gat[(int64_t)i1 * g.ldg + col];
+            }
+            e4[e] = x;
+          }
+          v = f32x4{e4[0], e4[1], e4[2], e4[3]};
+        }
+      }
+      *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = v;
+    }
+    __syncthreads();
+  }
+
   // Epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
   // (One straight-line body per MFMA tile, no `continue`: a loop over the tiles that hipcc does not
   // fully unroll indexes `acc` dynamically and moves all accumulators to scratch memory.)
@@ -273,6 +322,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
           if (atomic) {
             atomicAdd(cp, v);
           } else {
+            if (gather) v += lds[(row - m0) * BN + (col - n0)];
             if (g.epi == EPI_LEAKY_DROPOUT) {
               float keep;
               if (g.keep) {
@@ -371,6 +421,7 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
     int row = (int)(i / g.N), col = (int)(i - (int64_t)row * g.N);
     float* cp = g.C + (int64_t)row * g.ldc + col;
     float v = *cp + (g.bias ? g.bias[col] : 0.f);
+    if (g.gat) v += gemm_gather2(g, row, col);
     if (g.epi == EPI_LEAKY_DROPOUT) {
       float keep;
       if (g.keep) keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
@@ -443,14 +494,15 @@ extern "C" int dpc_gemm_streamk_config(int blocks) {
   return DPC_OK;
 }
 
-extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
-                            const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
-                            const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
-                            const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
-                            const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
-                            void* stream) {
+static int gemm_impl(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                     const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                     const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
+                     const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
+                     const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
+                     const float* gat, int64_t ldg, const int32_t* gidx, void* stream) {
   DPC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return DPC_OK;
+  DPC_CHECK_ARG(!gat || (gidx && ldg >= N && beta == 0.f), "gemm: row gather needs ids, ldg >= N and beta == 0");
   DPC_CHECK_ARG(A && B && C, "gemm: null operand");
   DPC_CHECK_ARG(a_rs == 1 || a_cs == 1, "gemm: A needs one unit stride");
   DPC_CHECK_ARG(b_rs == 1 || b_cs == 1, "gemm: B needs one unit stride");
@@ -470,6 +522,7 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   bool a_kc = (a_cs == 1), b_kc = (b_rs == 1);
   DPC_CHECK_ARG(!kscale || !a_kc, "gemm: kscale needs an m-contiguous A (the weight-gradient product)");
   g.kscale = kscale;
+  g.gat = gat; g.ldg = ldg; g.gidx = gidx;
   int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
   g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
@@ -499,7 +552,7 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     splitk = 1;
     const bool can_split = !g_deterministic && (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && bm == 64 && bn == 64 && K >= 512;
     if (can_split && g_streamk_blocks >= 0) {
-      const bool deferred = (epi != EPI_NONE || bias);
+      const bool deferred = (epi != EPI_NONE || bias || gat);
       const double nb = (double)blocks;
       const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv(blocks, 256) : nb / 256.0 + 0.3);
       const double t_plain = c * ((double)K * (nb <= 256.0 ? 0.021 : 0.0175) + 1.0) + 6.0;
@@ -512,7 +565,7 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       else if (t_sk < 0.95 * t_plain) streamk = sk_blocks;
     } else if (can_split) {
       // split-K: tiles x sp blocks, each tile's K range cut into sp equal chunks
-      const bool deferred = (epi != EPI_NONE || bias);
+      const bool deferred = (epi != EPI_NONE || bias || gat);
       double best = 1e30;
       int64_t maxs = K / 256;
       if (maxs > 32) maxs = 32;
@@ -526,11 +579,11 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       }
     }
   }
-  if (splitk > 1 && (epi != EPI_NONE || bias)) {
+  if (splitk > 1 && (epi != EPI_NONE || bias || gat)) {
     DPC_CHECK_ARG(beta == 0.f, "gemm: split-K with an epilogue needs beta == 0");
     deferred_epi = true;
   }
-  if (streamk > 0 && (epi != EPI_NONE || bias)) deferred_epi = true;
+  if (streamk > 0 && (epi != EPI_NONE || bias || gat)) deferred_epi = true;
   DPC_CHECK_ARG(splitk == 1 || beta == 0.f || beta == 1.f, "gemm: split-K needs beta in {0,1}");
   g.splitk = splitk;
   int ktiles = (int)dpc_cdiv(K, BK);
@@ -542,7 +595,7 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     g.beta = 1.f;   // accumulate into the zeroed C
   }
   GemmArgs full = g;
-  if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; }
+  if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; g.gat = nullptr; }
   if (streamk > 0) {
     int64_t units = blocks * ktiles;
     if (streamk > units) streamk = (int)units;
@@ -556,4 +609,27 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(dpc_grid((int64_t)M * N, 256)), dim3(256), 0, st, full);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
+}
+
+extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                            const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                            const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
+                            const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
+                            const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
+                            void* stream) {
+  return gemm_impl(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, epi, aux_out, ld_aux_out, aux_in,
+                   ld_aux_in, keep, ld_keep, rng, site, leak, splitk, kscale, nullptr, 0, nullptr, stream);
+}
+
+// Linear over an input whose trailing columns are a one-/two-hot conditional vector (the generator's
+// input cat([z, cond]) and the Residual blocks' cat([out, input]), dp_cgan.py:83,606): A and B cover the
+// dense columns only, and the hot columns' share of x W^T - the sum of those columns of W - is added
+// from gat = W[:, cond columns]^T [C, ldg] by row ids gidx int32 [M][2] (negative = none).
+extern "C" int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                                   const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, const float* bias,
+                                   int epi, const float* gat, int64_t ldg, const int32_t* gidx, void* stream) {
+  DPC_CHECK_ARG(gat && gidx, "gemm_gather: null pointer");
+  DPC_CHECK_ARG(epi == EPI_NONE || epi == EPI_RELU, "gemm_gather: epilogue must be none or ReLU");
+  return gemm_impl(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, 0.f, C, ldc, bias, epi, nullptr, 0, nullptr, 0, nullptr, 0,
+                   nullptr, 0, 0.2f, 0, nullptr, gat, ldg, gidx, stream);
 }

@@ -71,6 +71,7 @@ class FlatParams(object):
         self.t = torch.zeros(1, dtype=torch.int32, device=device)
         seg = [self.offsets[k] for k in self.keys] + [off]
         self.seg_off = torch.tensor(seg, dtype=torch.int64, device=device)
+        self.loaded = True       # parameters were written from outside (init, load): derived copies are stale
 
     def view(self, buf, k):
         o = self.offsets[k]
@@ -85,6 +86,7 @@ class FlatParams(object):
     def load(self, sd):
         for k in self.keys:
             self.P(k).copy_(torch.as_tensor(sd[k]).to(self.p.device, torch.float32))
+        self.loaded = True
 
     def state_dict(self):
         return {k: self.P(k).detach().clone() for k in self.keys}
@@ -130,6 +132,10 @@ class GenContext(object):
         self.val_idx = torch.zeros(B, device=d, dtype=torch.int64)
         self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
         self.gcount = torch.zeros(B, device=d, dtype=torch.int64)
+        # (row, hot id) pairs of sel sorted by id (ops.hot_sort): the backward's cond-column row sums
+        self.order = torch.zeros(2 * B, device=d, dtype=torch.int32)
+        self.sid = torch.zeros(2 * B, device=d, dtype=torch.int32)
+        self.n_items = torch.zeros(1, device=d, dtype=torch.int32)
         maxF = max(eng.gdim + [1])
         # one BatchNorm-sum workspace per layer (the deferred running-statistics update re-reads them)
         self.part = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in eng.gdim]
@@ -138,11 +144,12 @@ class GenContext(object):
 
 class StepEngine(object):
     GP_GRAM = None      # test hook: True / False overrides the automatic choice of the penalty's form
+    SPARSE_COND = None  # test hook: False keeps the cond columns inside the generator's dense products
 
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
                  private=False, seed=0, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
-                 weight_clip=None, gp_gram=None):
+                 weight_clip=None, gp_gram=None, sparse_cond=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
         self.span_info_np = np.asarray(span_info, dtype=np.int32).reshape(-1, 3)
@@ -191,6 +198,28 @@ class StepEngine(object):
                    ('seq.%d.bn.weight' % l, (self.gdim[l],)), ('seq.%d.bn.bias' % l, (self.gdim[l],))]
         gs += [('seq.%d.weight' % L, (self.Dd, self.Wtot)), ('seq.%d.bias' % L, (self.Dd,))]
         self.gen = FlatParams(gs, d)
+        # The cond vector is one-/two-hot (data_sampler.py:284-330, :348-363): its columns of every
+        # generator Linear stay off the matrix cores.  Forward: the GEMM covers the dense input columns
+        # and its epilogue adds the hot columns of W from WcT[l] = W_l[:, cond columns]^T by the row ids in
+        # GenContext.sel.  Backward: the cond columns of dW_l are row sums of dZ_l scattered by the same
+        # ids into dWcT[l] (zeroed with the gradient buffer: one fill), then transposed into place.
+        if sparse_cond is None:
+            sparse_cond = StepEngine.SPARSE_COND
+        self.sparse_cond = self.nd > 0 and self.C <= 15360 and (True if sparse_cond is None else bool(sparse_cond))
+        outs = self.gdim + [self.Dd]
+        if self.sparse_cond:
+            ext = [(self.C * w + 3) // 4 * 4 for w in outs]
+            gx = torch.zeros(self.gen.n + sum(ext), device=d)
+            self.gen.g = gx[:self.gen.n]
+            self._gen_gx = gx
+            self.dWcT, off = [], self.gen.n
+            for w, e in zip(outs, ext):
+                self.dWcT.append(gx[off:off + self.C * w].view(self.C, w))
+                off += e
+            self.WcT = [torch.zeros(self.C, (w + 3) // 4 * 4, device=d)[:, :w] for w in outs]     # rows 16-byte aligned
+        else:
+            self._gen_gx = self.gen.g
+        self._wct_stale = True
         ds, k = [], self.K0
         for i, w in enumerate(self.ddim):
             ds += [('seq.%d.weight' % (3 * i), (w, k)), ('seq.%d.bias' % (3 * i), (w,))]
@@ -358,6 +387,7 @@ class StepEngine(object):
     def load_generator_state_dict(self, sd):
         """Accepts the reference Generator's state_dict (keys/shapes of SURVEY 3.5)."""
         self.gen.load(sd)
+        self._wct_stale = True
         for k in self.bn_run:
             if k in sd:
                 self.bn_run[k].copy_(torch.as_tensor(sd[k]).to(self.dev, torch.float32))
@@ -398,6 +428,8 @@ class StepEngine(object):
             c.mask.copy_(inj['mask'])
             cv.copy_(c.cond)
             fake_c.copy_(c.cond)
+            if self.sparse_cond:
+                ops.cond_to_sel(c.cond, c.sel)
         else:
             s = self.sampler
             ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv, fake_c], c.mask, c.pair_id,
@@ -421,14 +453,45 @@ class StepEngine(object):
                                rng=self.rng, cntblk=s.cntblk, site=ops.SITE_ROWPICK + self._so)
                 ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=C)
 
+    def _gen_weight(self, l):
+        return self.gen.P('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
+
+    def _refresh_wct(self):
+        """WcT[l] = W_l[:, cond columns]^T for every generator Linear, one launch."""
+        if self.sparse_cond:
+            ops.transpose_slices([(self._gen_weight(l)[:, -self.C:], self.WcT[l]) for l in range(self.L + 1)])
+        self._wct_stale = False
+
+    def _gen_linear(self, c, l, out, bias):
+        """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear)."""
+        W = self._gen_weight(l)
+        if not self.sparse_cond:
+            ops.gemm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias)
+            return
+        if self._wct_stale or self.gen.loaded:       # parameters were (re)loaded outside an optimiser step
+            self.gen.loaded = False
+            self._refresh_wct()
+        ops.gemm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
+                        bias=bias)
+
+    def _gen_dweight(self, c, l, dy, part):
+        """dW_l (+)= dy^T Hg[:, start[l]:] into the zeroed gradient buffer, and the bias gradient."""
+        gw = self.gen.G('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
+        gb = self.gen.G('seq.%d.fc.bias' % l if l < self.L else 'seq.%d.bias' % self.L)
+        if self.sparse_cond and not ops.DETERMINISTIC:
+            ops.gemm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
+            ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
+        else:
+            ops.gemm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
+        self._colsum(dy, gb.view(1, -1), part=part)
+
     def _gen_forward(self, c, running=True):
         """Generator forward into context ``c``.  ``running`` False leaves BatchNorm's running
         statistics alone (``_bn_running`` applies the update later, from the column sums kept in c.part)."""
         g = self.gen
         count = float(self.gB)
         for l in range(self.L):
-            x = c.Hg[:, self.start[l]:]
-            ops.gemm(x, g.P('seq.%d.fc.weight' % l), c.Z[l], trans_b=True, bias=g.P('seq.%d.fc.bias' % l))
+            self._gen_linear(c, l, c.Z[l], g.P('seq.%d.fc.bias' % l))
             R = ops.colreduce_partial(0, c.Z[l], c.part[l])
             c.part_R[l] = R
             nel = R * 2 * self.gdim[l]
@@ -440,7 +503,7 @@ class StepEngine(object):
                             g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
         if running:
             self.bn_batches += 1
-        ops.gemm(c.Hg, g.P('seq.%d.weight' % self.L), c.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
+        self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
 
     def _gen_forward_pair(self, ca, cb):
         """Two generator forwards in lockstep (the last discriminator update's and the generator
@@ -451,10 +514,10 @@ class StepEngine(object):
         count = float(self.gB)
         for l in range(self.L):
             F = self.gdim[l]
-            W, b = g.P('seq.%d.fc.weight' % l), g.P('seq.%d.fc.bias' % l)
+            b = g.P('seq.%d.fc.bias' % l)
             R = 0
             for i, c in enumerate((ca, cb)):          # same shape, hence the same R: the two sets lie back to back
-                ops.gemm(c.Hg[:, self.start[l]:], W, c.Z[l], trans_b=True, bias=b)
+                self._gen_linear(c, l, c.Z[l], b)
                 R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
             self._allreduce(self.pair_part[:2 * R * 2 * F])
             for i, c in enumerate((ca, cb)):
@@ -465,7 +528,7 @@ class StepEngine(object):
                                 g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
         self.bn_batches += 2
         for c in (ca, cb):
-            ops.gemm(c.Hg, g.P('seq.%d.weight' % self.L), c.fake, trans_b=True, bias=g.P('seq.%d.bias' % self.L))
+            self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
 
     def _bn_running(self, c):
         """The running-statistics update a ``_gen_forward(c, running=False)`` left out, in its place in
@@ -737,8 +800,11 @@ class StepEngine(object):
         gradient buffer, z / cond inputs, generator forward, output activation."""
         self._so = 0 if sub is None else 64 * sub
         c = self.cg
-        self.gen.g.zero_()   # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
+        self._gen_gx.zero_()   # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
         self._draw_inputs(inj, need_real=False, c=c)
+        if self.sparse_cond:
+            with self._fork(1):      # beside the forward; the backward's weight gradients read it
+                ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._gen_forward(c, running=running)
         self._activate(inj, c)
 
@@ -747,6 +813,7 @@ class StepEngine(object):
         self._k = 0
         self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
+        self._join()
         self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3)
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
@@ -760,8 +827,7 @@ class StepEngine(object):
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
         with self._fork(0) as part:
-            ops.gemm(self.dfake, c.Hg, g.G('seq.%d.weight' % L), trans_a=True, beta=1.0)
-            self._colsum(self.dfake, g.G('seq.%d.bias' % L).view(1, -1), part=part)
+            self._gen_dweight(c, L, self.dfake, part)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
         count = float(self.gB)
@@ -776,12 +842,15 @@ class StepEngine(object):
                             dgamma, count, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
             with self._fork((L - l) % 2) as part:
-                ops.gemm(self.dZ[l], c.Hg[:, self.start[l]:], g.G('seq.%d.fc.weight' % l), trans_a=True, beta=1.0)
-                self._colsum(self.dZ[l], g.G('seq.%d.fc.bias' % l).view(1, -1), part=part)
+                self._gen_dweight(c, l, self.dZ[l], part)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
                 ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
         self._join()
+        if self.sparse_cond and not ops.DETERMINISTIC:
+            # the scattered cond-column gradients into their places in the flat gradient buffer
+            ops.transpose_slices([(self.dWcT[l], self.gen.G('seq.%d.fc.weight' % l if l < L else 'seq.%d.weight' % L)[:, -self.C:])
+                                  for l in range(L + 1)])
         if update:
             self._gen_update()
         if sub is None:
@@ -797,6 +866,7 @@ class StepEngine(object):
                 g.G('seq.%d.bn.bias' % l).mul_(1.0 / self.dist.world)
         self._allreduce(g.g)
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
+        self._refresh_wct()
 
     def train_step(self, d_steps=1):
         """``d_steps`` discriminator updates and one generator update (one iteration of the
@@ -811,8 +881,10 @@ class StepEngine(object):
             self._so = 64 * last
             self._draw_inputs({}, need_real=True, c=self.cd)
             self._so = 64 * d_steps
-            self.gen.g.zero_()
+            self._gen_gx.zero_()
             self._draw_inputs({}, need_real=False, c=self.cg)
+            if self.sparse_cond:
+                ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
             self._gen_forward_pair(self.cd, self.cg)
             self._so = 64 * last
             self._activate({}, self.cd, raw=True)
@@ -865,6 +937,8 @@ class StepEngine(object):
         ops.fill(zv, ops.FILL_NORMAL, self.rng, ops.SITE_Z, 0.0, 1.0)
         if self.has_cond:
             cv.copy_(cond)
+            if self.sparse_cond:
+                ops.cond_to_sel(cv, c.sel)
         self._gen_forward(c)
         out = torch.empty(self.B, self.Dd, device=self.dev)
         ops.apply_activate_fwd(c.fake, out, self.spans, rng=self.rng)

@@ -50,9 +50,14 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+DETERMINISTIC = False
+
+
 def set_deterministic(on=True):
-    """Bit-reproducible steps (no split-K atomics in the GEMMs), at some cost in speed."""
+    """Bit-reproducible steps (no split-K atomics in the GEMMs, no scatter atomics), at some cost in speed."""
+    global DETERMINISTIC
     lib().call('dpc_set_deterministic', int(bool(on)))
+    DETERMINISTIC = bool(on)
 
 
 def new_rng(seed, device):
@@ -106,6 +111,78 @@ def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, 
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b)))
     return C
+
+
+def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE):
+    """C = epi(A @ op(B) + bias + gat[gidx[:,0]] + gat[gidx[:,1]]) (ids < 0 skipped): Linear over the dense
+    columns of an input whose trailing cond columns are one-/two-hot; gat = W[:, cond columns]^T."""
+    for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (gat, 'gat')):
+        _chk(t, torch.float32, n)
+    _chk(gidx, torch.int32, 'gidx')
+    a_rs, a_cs = _mat_strides(A, False)
+    b_rs, b_cs = _mat_strides(B, trans_b)
+    M, K = A.shape
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2 or C.shape[0] != M or C.shape[1] != N or gat.shape[1] != N or gidx.shape[0] != M or gidx.shape[1] != 2:
+        raise ValueError('gemm_gather shape mismatch')
+    if not gidx.is_contiguous():
+        raise ValueError('gemm_gather: gidx must be contiguous [M, 2]')
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call('dpc_gemm_f32_gather', M, N, K, 1.0, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, _p(C), _ld(C), _p(bias), epi,
+               _p(gat), _ld(gat), _p(gidx), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, False, trans_b)))
+    return C
+
+
+def cond_to_sel(cond, sel, bad=None):
+    _chk(cond, torch.float32, 'cond')
+    _chk(sel, torch.int32, 'sel')
+    _chk(bad, torch.int32, 'bad')
+    if sel.shape[0] != cond.shape[0] or sel.shape[1] != 2 or not sel.is_contiguous():
+        raise ValueError('cond_to_sel: sel must be a contiguous [B, 2] tensor')
+    lib().call('dpc_cond_to_sel', _p(cond), _ld(cond), cond.shape[0], cond.shape[1], _p(sel), _p(bad), _stream())
+    return sel
+
+
+def transpose_slices(pairs):
+    """pairs: [(src [r, c] view, dst [c, r] view)], up to 8; dst = src^T in one launch."""
+    L = len(pairs)
+    for s_, d_ in pairs:
+        _chk(s_, torch.float32, 'src')
+        _chk(d_, torch.float32, 'dst')
+        if d_.shape[0] != s_.shape[1] or d_.shape[1] != s_.shape[0]:
+            raise ValueError('transpose_slices: dst must be the transposed shape of src')
+    P = ctypes.c_void_p * L
+    I64 = ctypes.c_int64 * L
+    I32 = ctypes.c_int * L
+    lib().call('dpc_transpose_slices', L, P(*[s_.data_ptr() for s_, _ in pairs]), I64(*[_ld(s_) for s_, _ in pairs]),
+               I32(*[s_.shape[0] for s_, _ in pairs]), I32(*[s_.shape[1] for s_, _ in pairs]),
+               P(*[d_.data_ptr() for _, d_ in pairs]), I64(*[_ld(d_) for _, d_ in pairs]), _stream())
+
+
+def hot_sort(sel, C, order, sid, n_items):
+    """Counting sort of the (row, hot id) pairs of sel [B, 2] by id -> order, sid [2B], n_items [1] (all int32)."""
+    for t, n in ((sel, 'sel'), (order, 'order'), (sid, 'sid'), (n_items, 'n_items')):
+        _chk(t, torch.int32, n)
+    B = sel.shape[0]
+    if not sel.is_contiguous() or order.numel() < 2 * B or sid.numel() < 2 * B:
+        raise ValueError('hot_sort: sel must be contiguous [B, 2], order / sid hold 2B entries')
+    lib().call('dpc_hot_sort', _p(sel), B, int(C), _p(order), _p(sid), _p(n_items), _stream())
+
+
+def hot_rows_sum(dy, order, sid, n_items, acc):
+    """acc[id] += sum of the rows of dy listed for id (sorted pairs of hot_sort)."""
+    _chk(dy, torch.float32, 'dy')
+    _chk(acc, torch.float32, 'acc')
+    if acc.shape[1] != dy.shape[1]:
+        raise ValueError('hot_rows_sum: shape mismatch')
+    lib().call('dpc_hot_rows_sum', _p(dy), _ld(dy), dy.shape[1], _p(order), _p(sid), _p(n_items), order.numel(), _p(acc),
+               _ld(acc), _stream())
 
 
 def apply_activate_fwd(x, y, spans, exp_noise=None, rng=None, site=SITE_GUMBEL, tau=0.2):

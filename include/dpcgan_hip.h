@@ -62,6 +62,16 @@ int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep, const uint64_t* rng,
                  uint32_t site, float leak, int splitk, const float* kscale, void* stream);
 
+/* Linear over an input whose trailing columns are a one-/two-hot conditional vector (the generator's
+ * cat([z, cond]) input, dp_cgan.py:606, and Residual's cat([out, input]), :83): A and B cover the dense
+ * columns only; the hot columns' share of x W^T - the sum of those columns of W - is added in the
+ * epilogue from gat = W[:, cond columns]^T (fp32 [C][ldg]) by row ids gidx int32 [M][2] (negative =
+ * none).  C = epi(alpha * A.B + bias + gat[gidx[m][0]] + gat[gidx[m][1]]), epi 0 or 3 (ReLU). */
+int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                        const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
+                        const float* bias, int epi, const float* gat, int64_t ldg, const int32_t* gidx,
+                        void* stream);
+
 /* tuning / test hook: force the GEMM block tile (0 automatic, 64 = 64x64, 128 = 128x128,
  * 12864 = 128x64, 64128 = 64x128).  Host-side state. */
 int dpc_gemm_config(int force_tile);
@@ -134,6 +144,27 @@ int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_
  * [0, 2^bits) cycle-walked into [0, B); keys_ws is unused (kept for ABI stability, may be NULL). */
 int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
                     void* stream);
+
+/* ---- the conditional vector as one / two hot columns per row -------------------------------- */
+/* sel[b][0..1] = ascending column ids of the nonzero entries of cond[b, :] (what sample_condvec_pair,
+ * data_sampler.py:284-330, and sample_original_condvec, :348-363, set), -1 padded.  *bad (device
+ * int32, nullable) counts rows that are not one-/two-hot {0,1} vectors. */
+int dpc_cond_to_sel(const float* cond, int64_t ld, int64_t B, int C, int32_t* sel, int32_t* bad,
+                    void* stream);
+/* Up to 8 transposes in one launch, dst_k[c][r] = src_k[r][c]; all array arguments are HOST arrays of
+ * nslices entries.  Keeps W[:, cond columns]^T of the generator layers current (gat of
+ * dpc_gemm_f32_gather) and writes the cond-column gradients (dpc_hot_rows_sum) back in dW's layout. */
+int dpc_transpose_slices(int nslices, const float* const* src, const int64_t* ld_src, const int* rows,
+                         const int* cols, float* const* dst, const int64_t* ld_dst, void* stream);
+/* Counting sort of the (row, hot id) pairs of sel int32 [B][2] by id: order[p] = row, sid[p] = id for
+ * p < *n_items (device int32), ids ascending; order / sid hold 2B entries; C <= 15360. */
+int dpc_hot_sort(const int32_t* sel, int64_t B, int C, int32_t* order, int32_t* sid, int32_t* n_items,
+                 void* stream);
+/* acc[id][j] += sum of dy[row][j] over the sorted pairs: the cond columns of dW = dY^T X (autograd of
+ * the Linear layers above), transposed [C][ld_acc].  One fp32 atomic per id change and block: not
+ * bit-reproducible.  max_items = capacity of order / sid. */
+int dpc_hot_rows_sum(const float* dy, int64_t ld, int F, const int32_t* order, const int32_t* sid,
+                     const int32_t* n_items, int64_t max_items, float* acc, int64_t ld_acc, void* stream);
 
 /* ---- DataTransformer.transform (data_transformer.py:102-150) -------------------------------- */
 /* tab fp64 [4][K] = mu, sigma, precision_cholesky, A (A = the x-independent part of sklearn's

@@ -76,7 +76,10 @@ def replay(dist, dev):
     if r == 0:
         for k in tr.z.files:
             if k.startswith('gen_final/') and 'running' in k:
-                close(sd[k[len('gen_final/'):]], tr.z[k], what=k)
+                sc = None       # as in test_engine_gpu: a batch mean near zero is judged on the feature's spread
+                if k.endswith('running_mean'):
+                    sc = max(np.abs(tr.z[k]).max(), float(np.sqrt(tr.z[k.replace('running_mean', 'running_var')]).max()))
+                close(sd[k[len('gen_final/'):]], tr.z[k], scale=sc, what=k)
 
 
 def graph(dist, dev, mode):

@@ -11,14 +11,18 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
-@pytest.fixture(autouse=True, params=['penalty-direct', 'penalty-gram'])
-def penalty_form(request):
-    """Every test of this file runs with both forms of the discriminator update's first layer: the
-    direct one (interpolates, g0 = u W1 and v0 formed) and the Gram one (W1 W1^T; engine._d_back)."""
+@pytest.fixture(autouse=True, params=['penalty-direct', 'penalty-gram', 'penalty-gram,dense-cond'])
+def step_form(request):
+    """Every test of this file runs with both forms of the discriminator update's first layer - the
+    direct one (interpolates, g0 = u W1 and v0 formed) and the Gram one (W1 W1^T; engine._d_back) - and
+    with the generator's cond columns as row gathers / scatters (the default) or inside the dense
+    products."""
     from dp_cgans_amd.engine import StepEngine
-    StepEngine.GP_GRAM = request.param == 'penalty-gram'
+    StepEngine.GP_GRAM = 'penalty-gram' in request.param
+    StepEngine.SPARSE_COND = False if 'dense-cond' in request.param else None
     yield request.param
     StepEngine.GP_GRAM = None
+    StepEngine.SPARSE_COND = None
 
 
 def close(a, b, rtol=RTOL, what='', scale=None):

@@ -409,6 +409,81 @@ def test_encode_bit_exact_against_reference(ops):
 
 
 # ------------------------------------------------------------------------------------------------
+# cond vector as hot columns
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,C,F,Kd', [(500, 38, 256, 128), (37, 9, 21, 13), (8192, 276, 335, 640), (64, 300, 64, 4900)])
+def test_gather_gemm_equals_dense_linear_over_hot_columns(ops, B, C, F, Kd):
+    """Linear over [dense | cond] == GEMM over the dense columns + gathered hot columns of W (two-hot,
+    one-hot and empty rows), with bias and ReLU; also on a split-K shape (deferred epilogue)."""
+    g = torch.Generator().manual_seed(B + C)
+    d_ = dev()
+    x = torch.randn(B, Kd, generator=g)
+    W = torch.randn(F, Kd + C, generator=g) / (Kd + C) ** 0.5
+    b = torch.randn(F, generator=g) * 0.1
+    cond = torch.zeros(B, C)
+    i0 = torch.randint(0, C, (B,), generator=g)
+    i1 = (i0 + 1 + torch.randint(0, C - 1, (B,), generator=g)) % C
+    cond[torch.arange(B), i0] = 1
+    two = torch.rand(B, generator=g) < 0.7
+    cond[torch.arange(B)[two], i1[two]] = 1
+    cond[0] = 0                                   # a row without any hot column
+    inp = torch.cat([x, cond], 1).to(d_)          # [B, Kd + C] as the generator's Hg holds it
+    Wd = W.to(d_)
+    sel = torch.full((B, 2), -7, dtype=torch.int32, device=d_)
+    bad = torch.zeros(1, dtype=torch.int32, device=d_)
+    ops.cond_to_sel(inp[:, Kd:], sel, bad)
+    assert int(bad) == 0
+    want = torch.full((B, 2), -1, dtype=torch.int64)
+    for r in range(B):
+        nz = torch.nonzero(cond[r]).reshape(-1)
+        want[r, :len(nz)] = nz
+    assert torch.equal(sel.cpu().long(), want)
+    WcT = torch.empty(C, F, device=d_)
+    ops.transpose_slices([(Wd[:, Kd:], WcT)])
+    assert torch.equal(WcT.cpu(), W[:, Kd:].t())
+    ref = inp.cpu().double() @ W.double().t() + b.double()
+    for epi in (ops.EPI_NONE, ops.EPI_RELU):
+        out = torch.full((B, F), float('nan'), device=d_)
+        ops.gemm_gather(inp[:, :Kd], Wd[:, :Kd], out, WcT, sel, bias=b.to(d_), epi=epi)
+        close(out, torch.relu(ref) if epi else ref, what='gather gemm epi %d' % epi)
+    # rows that are not one-/two-hot are counted
+    inp[3, Kd:Kd + 3] = 1
+    inp[5, Kd] = 0.5
+    ops.cond_to_sel(inp[:, Kd:], sel, bad)
+    assert int(bad) == 2
+
+
+@pytest.mark.parametrize('B,C,F', [(500, 38, 256), (8192, 276, 335), (33, 5, 7)])
+def test_hot_sort_and_row_sums_are_the_cond_block_of_the_weight_gradient(ops, B, C, F):
+    g = torch.Generator().manual_seed(B)
+    d_ = dev()
+    dy = torch.randn(B, F, generator=g)
+    sel = torch.stack([torch.randint(-1, C, (B,), generator=g), torch.randint(-1, C, (B,), generator=g)], 1).to(torch.int32)
+    cond = torch.zeros(B, C, dtype=torch.float64)
+    for h in range(2):
+        ok = sel[:, h] >= 0
+        cond[torch.arange(B)[ok], sel[ok, h].long()] += 1
+    ref = dy.double().t() @ cond                 # [F, C] = the cond columns of dW = dY^T X
+    acc = torch.zeros(C, F, device=d_)
+    order = torch.full((2 * B,), -1, dtype=torch.int32, device=d_)
+    sid = torch.full((2 * B,), -1, dtype=torch.int32, device=d_)
+    n_items = torch.zeros(1, dtype=torch.int32, device=d_)
+    ops.hot_sort(sel.to(d_), C, order, sid, n_items)
+    m = int(n_items)
+    assert m == int((sel >= 0).sum())
+    so, ss = order.cpu()[:m].long(), sid.cpu()[:m].long()
+    assert bool((ss[1:] >= ss[:-1]).all())                                  # ids ascending
+    pairs = sorted((int(i), int(r)) for r in range(B) for i in sel[r].tolist() if i >= 0)
+    assert sorted(zip(ss.tolist(), so.tolist())) == pairs                   # a permutation of the (id, row) pairs
+    ops.hot_rows_sum(dy.to(d_), order, sid, n_items, acc)
+    close(acc, ref.t(), what='scatter')
+    dW = torch.full((F, C + 11), 7.0, device=d_)
+    ops.transpose_slices([(acc, dW[:, 11:])])
+    close(dW[:, 11:], ref, what='scatter transposed into dW')
+    assert float(dW[:, :11].min()) == 7.0
+
+
+# ------------------------------------------------------------------------------------------------
 # BatchNorm pieces
 # ------------------------------------------------------------------------------------------------
 def test_batchnorm_relu_forward_backward(ops):
