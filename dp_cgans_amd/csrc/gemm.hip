@@ -236,6 +236,32 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   // loads in flight with counted s_waitcnt vmcnt(N) instead of draining to 0 at every control-flow
   // join.  The loads of tile t+PF are issued before the MFMAs of tile t and land in LDS PF-1
   // iterations later: with ~1 block per CU nothing else hides the 1-2 us L2/HBM latency.
+  // Row gather (see GemmArgs::gat): the block's BM x BN share of gat[gidx[m][0]] + gat[gidx[m][1]] reaches
+  // the epilogue through LDS, loaded with 16-byte loads along the rows of gat (the MFMA output layout
+  // holds one column per lane: gathering from there would be 2 x 16 scalar loads per lane and tile).
+  // For 64x64 tiles the loads are issued HERE, before the K loop, and sit in registers until the loop
+  // is done: ids -> rows of gat is a chain of two dependent L2 round trips, longer than the whole
+  // K loop of the generator's first layer (K = 128).
+  const bool gather = (g.gat != nullptr) && !atomic;
+  constexpr int GV = BN / 4;
+  constexpr bool GPRE = (BM * BN <= 4096);
+  constexpr int GQ = GPRE ? (BM * GV) / 256 : 1;
+  const bool gvec = gather && ((g.ldg & 3) == 0) && (((uintptr_t)g.gat & 15) == 0) && (n0 + BN <= g.N);
+  f32x4 gv[GQ];
+  if (GPRE && gvec) {
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      const int idx = threadIdx.x + q * 256;
+      const int r = idx / GV, c4 = (idx - r * GV) * 4;
+      const int row = min(m0 + r, g.M - 1);
+      const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
+      if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
+      gv[q] = v;
+    }
+  }
+
   if (nmain > 0) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
@@ -270,39 +296,42 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     __syncthreads();
   }
 
-  // Row gather (see GemmArgs::gat): the block stages its BM x BN share of gat[gidx[m][0]] + gat[gidx[m][1]]
-  // in LDS with 16-byte loads along the rows of gat (the MFMA output layout holds one column per lane:
-  // gathering from there would be 2 x 16 scalar loads per lane and tile, more than a short K loop issues).
-  const bool gather = (g.gat != nullptr) && !atomic;
   if (gather) {
     static_assert(BM * BN <= 2 * SA::SIZE + 2 * SB::SIZE, "gather image must fit the operand buffers");
-    constexpr int V = BN / 4;
-    const bool vec = ((g.ldg & 3) == 0) && (((uintptr_t)g.gat & 15) == 0) && (n0 + BN <= g.N);
-    for (int idx = threadIdx.x; idx < BM * V; idx += 256) {
-      const int r = idx / V, c4 = (idx - r * V) * 4;
-      const int row = m0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < g.M) {
-        const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
-        if (vec) {
-          if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
-          if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
-        } else {
-          float e4[4];
+    if (GPRE && gvec) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int col = n0 + c4 + e;
-            float x = 0.f;
-            if (col < g.N) {
-              if (i0 >= 0) x += g.gat[(int64_t)i0 * g.ldg + col];
-              if (i1 >= 0) x += g.gat[(int64_t)i1 * g.ldg + col];
-            }
-            e4[e] = x;
-          }
-          v = f32x4{e4[0], e4[1], e4[2], e4[3]};
-        }
+      for (int q = 0; q < GQ; ++q) {
+        const int idx = threadIdx.x + q * 256;
+        const int r = idx / GV, c4 = (idx - r * GV) * 4;
+        *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = gv[q];
       }
-      *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = v;
+    } else {
+      for (int idx = threadIdx.x; idx < BM * GV; idx += 256) {
+        const int r = idx / GV, c4 = (idx - r * GV) * 4;
+        const int row = m0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < g.M) {
+          const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
+          if (gvec) {
+            if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
+            if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
+          } else {
+            float e4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int col = n0 + c4 + e;
+              float x = 0.f;
+              if (col < g.N) {
+                if (i0 >= 0) x += g.gat[(int64_t)i0 * g.ldg + col];
+                if (i1 >= 0) x += g.gat[(int64_t)i1 * g.ldg + col];
+              }
+              e4[e] = x;
+            }
+            v = f32x4{e4[0], e4[1], e4[2], e4[3]};
+          }
+        }
+        *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = v;
+      }
     }
     __syncthreads();
   }

@@ -95,6 +95,24 @@ extern "C" int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int6
   return DPC_OK;
 }
 
+// BatchNorm1d statistics from the column sums, and the running-statistics update
+// running = (1 - momentum) * running + momentum * new.  One function with FMA contraction off: both
+// kernels that apply it (colreduce_finish_kernel and the fused BatchNorm forward) must agree to the bit.
+__device__ __forceinline__ void bn_stats(double s0, double s1, double count, float eps, float& mean, float& invstd,
+                                         float* run_mean, float* run_var, int f, float momentum) {
+#pragma clang fp contract(off)
+  const double meand = s0 / count;
+  double var = s1 / count - meand * meand;
+  if (var < 0.0) var = 0.0;
+  mean = (float)meand;
+  invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[f] = (1.f - momentum) * run_mean[f] + momentum * mean;
+    run_var[f] = (1.f - momentum) * run_var[f] + momentum * (float)unbiased;
+  }
+}
+
 // Finish a column reduction.  kind 0: BatchNorm statistics -> mean, invstd (+ running stats);
 // kind 1: plain sums -> out0 (float), accumulate optional; kind 2: two sums -> out0, out1 (dbeta, dgamma).
 __global__ __launch_bounds__(256) void colreduce_finish_kernel(const double* __restrict__ part, int R, int nout, int F,
@@ -127,16 +145,10 @@ __global__ __launch_bounds__(256) void colreduce_finish_kernel(const double* __r
   s0 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
   s1 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   if (kind == 0) {
-    double mean = s0 / count;
-    double var = s1 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    out0[f] = (float)mean;
-    out1[f] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) {
-      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      run_mean[f] = (1.f - momentum) * run_mean[f] + momentum * (float)mean;
-      run_var[f] = (1.f - momentum) * run_var[f] + momentum * (float)unbiased;
-    }
+    float mean, invstd;
+    bn_stats(s0, s1, count, eps, mean, invstd, run_mean, run_var, f, momentum);
+    out0[f] = mean;
+    out1[f] = invstd;
   } else {
     out0[f] = accumulate ? out0[f] + (float)s0 : (float)s0;
     if (nout == 2) out1[f] = accumulate ? out1[f] + (float)s1 : (float)s1;
@@ -209,6 +221,139 @@ extern "C" int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, in
   DPC_CHECK_ARG(B > 0 && F > 0 && count > 0.0, "bn_relu_bwd: bad shape");
   hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(dpc_grid(B * F, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y,
                      ldy, z, ldz, B, F, mean, invstd, gamma, dbeta, dgamma, (float)(1.0 / count), dz, lddz);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm + ReLU with the reduction's finish inside: a block owns a 64-column strip of a row chunk,
+// first adds the R row-chunk partials of its columns (what colreduce_finish_kernel does, same order:
+// lane rl takes chunks rl, rl+4, ..), then normalises its rows.  One kernel node less on the step's
+// critical path per BatchNorm (a node costs ~5 us whatever it does); the partials are re-read by
+// every row chunk's block from L2 (R*2*64 doubles = 64 KB per block at T1M).
+// Blocks of row chunk 0 write mean / invstd (the backward needs them) and update the running statistics.
+// ---------------------------------------------------------------------------------------------
+struct BnFusedArgs {
+  const float* z; int64_t ldz; float* y; int64_t ldy; int64_t B; int F;
+  const double* part; int R; double count; float eps, momentum;
+  const float* gamma; const float* beta;
+  float* mean_out; float* invstd_out; float* run_mean; float* run_var;
+  int64_t rows_per_block;
+};
+
+__device__ __forceinline__ void bn_strip_sums(const double* __restrict__ part, int R, int F, int f, int c, int rl,
+                                              double (*red)[4][64], double& s0, double& s1) {
+  s0 = 0.0; s1 = 0.0;
+  if (f < F) {
+#pragma unroll 4
+    for (int r = rl; r < R; r += 4) {
+      s0 += part[((int64_t)r * 2 + 0) * F + f];
+      s1 += part[((int64_t)r * 2 + 1) * F + f];
+    }
+  }
+  red[0][rl][c] = s0;
+  red[1][rl][c] = s1;
+  __syncthreads();
+  s0 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+  s1 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_fused_kernel(BnFusedArgs a) {
+  __shared__ double red[2][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + c;
+  double s0, s1;
+  bn_strip_sums(a.part, a.R, a.F, f, c, rl, red, s0, s1);
+  if (f >= a.F) return;
+  float mean, invstd;
+  const bool writer = blockIdx.y == 0 && rl == 0;
+  bn_stats(s0, s1, a.count, a.eps, mean, invstd, writer ? a.run_mean : nullptr, a.run_var, f, a.momentum);
+  if (writer) {
+    a.mean_out[f] = mean;
+    a.invstd_out[f] = invstd;
+  }
+  const float ga = a.gamma[f], be = a.beta[f];
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
+#pragma unroll 8
+  for (int64_t r = r0 + rl; r < r1; r += 4) {
+    const float v = (a.z[r * a.ldz + f] - mean) * invstd * ga + be;
+    a.y[r * a.ldy + f] = fmaxf(v, 0.f);
+  }
+}
+
+// part: the R x 2 x F partial sums of dpc_colreduce_partial mode 0 (all-reduced over ranks if any).
+extern "C" int dpc_bn_relu_fwd_fused(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F,
+                                     const double* part, int R, double count, float eps, float momentum,
+                                     const float* gamma, const float* beta, float* mean_out, float* invstd_out,
+                                     float* run_mean, float* run_var, void* stream) {
+  DPC_CHECK_ARG(z && y && part && gamma && beta && mean_out && invstd_out, "bn_relu_fwd_fused: null pointer");
+  DPC_CHECK_ARG(B > 0 && F > 0 && ldz >= F && ldy >= F && R >= 1 && count > 0.0, "bn_relu_fwd_fused: bad shape");
+  DPC_CHECK_ARG(!run_mean == !run_var, "bn_relu_fwd_fused: running mean and variance go together");
+  BnFusedArgs a;
+  a.z = z; a.ldz = ldz; a.y = y; a.ldy = ldy; a.B = B; a.F = F; a.part = part; a.R = R; a.count = count; a.eps = eps;
+  a.momentum = momentum; a.gamma = gamma; a.beta = beta; a.mean_out = mean_out; a.invstd_out = invstd_out;
+  a.run_mean = run_mean; a.run_var = run_var;
+  const int64_t strips = dpc_cdiv(F, 64);
+  int64_t chunks = dpc_cdiv(1024, strips);            // ~4 blocks per CU (256 measured slower: long serial row walks)
+  if (chunks > dpc_cdiv(B, 32)) chunks = dpc_cdiv(B, 32);
+  if (chunks < 1) chunks = 1;
+  a.rows_per_block = dpc_cdiv(B, chunks);
+  chunks = dpc_cdiv(B, a.rows_per_block);
+  hipLaunchKernelGGL(bn_relu_fwd_fused_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+struct BnBwdFusedArgs {
+  const float* dy; int64_t lddy; const float* y; int64_t ldy; const float* z; int64_t ldz; int64_t B; int F;
+  const double* part; int R; double count;
+  const float* mean; const float* invstd; const float* gamma;
+  float* dbeta; float* dgamma; float* dz; int64_t lddz;
+  int64_t rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(BnBwdFusedArgs a) {
+  __shared__ double red[2][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + c;
+  double s0, s1;
+  bn_strip_sums(a.part, a.R, a.F, f, c, rl, red, s0, s1);
+  if (f >= a.F) return;
+  const float db = (float)s0, dg = (float)s1;
+  if (blockIdx.y == 0 && rl == 0) {
+    a.dbeta[f] = db;
+    a.dgamma[f] = dg;
+  }
+  const float mu = a.mean[f], is = a.invstd[f], ga = a.gamma[f];
+  const float inv_count = (float)(1.0 / a.count);
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
+#pragma unroll 4
+  for (int64_t r = r0 + rl; r < r1; r += 4) {
+    const float dyh = a.y[r * a.ldy + f] > 0.f ? a.dy[r * a.lddy + f] : 0.f;
+    const float xh = (a.z[r * a.ldz + f] - mu) * is;
+    a.dz[r * a.lddz + f] = ga * is * (dyh - db * inv_count - xh * dg * inv_count);
+  }
+}
+
+// part: the R x 2 x F partial sums of dpc_colreduce_partial mode 2 (all-reduced over ranks if any);
+// writes dbeta, dgamma (= the finished sums) and dz as dpc_colreduce_finish kind 2 + dpc_bn_relu_bwd do.
+extern "C" int dpc_bn_relu_bwd_fused(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z,
+                                     int64_t ldz, int64_t B, int F, const double* part, int R, double count,
+                                     const float* mean, const float* invstd, const float* gamma, float* dbeta,
+                                     float* dgamma, float* dz, int64_t lddz, void* stream) {
+  DPC_CHECK_ARG(dy && y && z && part && mean && invstd && gamma && dbeta && dgamma && dz, "bn_relu_bwd_fused: null pointer");
+  DPC_CHECK_ARG(B > 0 && F > 0 && R >= 1 && count > 0.0, "bn_relu_bwd_fused: bad shape");
+  BnBwdFusedArgs a;
+  a.dy = dy; a.lddy = lddy; a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz; a.B = B; a.F = F; a.part = part; a.R = R;
+  a.count = count; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.dbeta = dbeta; a.dgamma = dgamma; a.dz = dz;
+  a.lddz = lddz;
+  const int64_t strips = dpc_cdiv(F, 64);
+  int64_t chunks = dpc_cdiv(1024, strips);
+  if (chunks > dpc_cdiv(B, 32)) chunks = dpc_cdiv(B, 32);
+  if (chunks < 1) chunks = 1;
+  a.rows_per_block = dpc_cdiv(B, chunks);
+  chunks = dpc_cdiv(B, a.rows_per_block);
+  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -496,11 +496,10 @@ class StepEngine(object):
             c.part_R[l] = R
             nel = R * 2 * self.gdim[l]
             self._allreduce(c.part[l][:nel])
-            ops.colreduce_finish(c.part[l], R, 2, self.gdim[l], 0, c.bn_mean[l], c.bn_invstd[l], count=count,
-                                 run_mean=self.bn_run['seq.%d.bn.running_mean' % l] if running else None,
-                                 run_var=self.bn_run['seq.%d.bn.running_var' % l] if running else None)
-            ops.bn_relu_fwd(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.bn_mean[l], c.bn_invstd[l],
-                            g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
+            ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.part[l], R, count,
+                                  g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l], c.bn_invstd[l],
+                                  run_mean=self.bn_run['seq.%d.bn.running_mean' % l] if running else None,
+                                  run_var=self.bn_run['seq.%d.bn.running_var' % l] if running else None)
         if running:
             self.bn_batches += 1
         self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
@@ -521,11 +520,11 @@ class StepEngine(object):
                 R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
             self._allreduce(self.pair_part[:2 * R * 2 * F])
             for i, c in enumerate((ca, cb)):
-                ops.colreduce_finish(self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, 2, F, 0, c.bn_mean[l],
-                                     c.bn_invstd[l], count=count, run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
-                                     run_var=self.bn_run['seq.%d.bn.running_var' % l])
-                ops.bn_relu_fwd(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.bn_mean[l], c.bn_invstd[l],
-                                g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l))
+                ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]],
+                                      self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, count,
+                                      g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l], c.bn_invstd[l],
+                                      run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
+                                      run_var=self.bn_run['seq.%d.bn.running_var' % l])
         self.bn_batches += 2
         for c in (ca, cb):
             self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
@@ -837,9 +836,8 @@ class StepEngine(object):
             R = ops.colreduce_partial(2, dy, self.part, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
             self._allreduce(self.part[:R * 2 * self.gdim[l]])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
-            ops.colreduce_finish(self.part, R, 2, self.gdim[l], 2, dbeta, dgamma)
-            ops.bn_relu_bwd(dy, yv, c.Z[l], c.bn_mean[l], c.bn_invstd[l], g.P('seq.%d.bn.weight' % l), dbeta,
-                            dgamma, count, self.dZ[l])
+            ops.bn_relu_bwd_fused(dy, yv, c.Z[l], self.part, R, count, c.bn_mean[l], c.bn_invstd[l],
+                                  g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
             with self._fork((L - l) % 2) as part:
                 self._gen_dweight(c, l, self.dZ[l], part)

@@ -328,6 +328,21 @@ def bn_relu_bwd(dy, y, z, mean, invstd, gamma, dbeta, dgamma, count, dz):
                _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), float(count), _p(dz), _ld(dz), _stream())
 
 
+def bn_relu_fwd_fused(z, y, part, R, count, gamma, beta, mean_out, invstd_out, run_mean=None, run_var=None, eps=1e-5,
+                      momentum=0.1):
+    """colreduce_finish (kind 0) + bn_relu_fwd in one launch."""
+    _chk(part, torch.float64, 'part')
+    lib().call('dpc_bn_relu_fwd_fused', _p(z), _ld(z), _p(y), _ld(y), z.shape[0], z.shape[1], _p(part), R, float(count),
+               eps, momentum, _p(gamma), _p(beta), _p(mean_out), _p(invstd_out), _p(run_mean), _p(run_var), _stream())
+
+
+def bn_relu_bwd_fused(dy, y, z, part, R, count, mean, invstd, gamma, dbeta, dgamma, dz):
+    """colreduce_finish (kind 2) + bn_relu_bwd in one launch."""
+    _chk(part, torch.float64, 'part')
+    lib().call('dpc_bn_relu_bwd_fused', _p(dy), _ld(dy), _p(y), _ld(y), _p(z), _ld(z), z.shape[0], z.shape[1], _p(part), R,
+               float(count), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _ld(dz), _stream())
+
+
 def disc_out_fwd(h, w, b, y, rowscale=None, slope=None, delta=None):
     """y = h.w + b; with delta also delta = rowscale[:,None] * w * slope (seed of the backward chain)."""
     lib().call('dpc_disc_out_fwd', _p(h), _ld(h), _p(w), _p(b), h.shape[0], h.shape[1], _p(y), _p(rowscale), _p(slope),

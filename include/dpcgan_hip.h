@@ -236,6 +236,20 @@ int dpc_bn_relu_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, 
                     int64_t ldz, int64_t B, int F, const float* mean, const float* invstd,
                     const float* gamma, const float* dbeta, const float* dgamma, double count,
                     float* dz, int64_t lddz, void* stream);
+/* The two calls above in one launch (a kernel node costs ~5 us on the step's critical path whatever it
+ * does): every block first finishes the reduction for its 64 columns from `part` (the R x 2 x F
+ * sums of dpc_colreduce_partial mode 0, all-reduced over ranks if any), then normalises its rows;
+ * mean_out / invstd_out and the running statistics (nullable) are written as dpc_colreduce_finish
+ * kind 0 does. */
+int dpc_bn_relu_fwd_fused(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F,
+                          const double* part, int R, double count, float eps, float momentum,
+                          const float* gamma, const float* beta, float* mean_out, float* invstd_out,
+                          float* run_mean, float* run_var, void* stream);
+/* Likewise for the backward: part = mode-2 sums; writes dbeta, dgamma and dz. */
+int dpc_bn_relu_bwd_fused(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z,
+                          int64_t ldz, int64_t B, int F, const double* part, int R, double count,
+                          const float* mean, const float* invstd, const float* gamma, float* dbeta,
+                          float* dgamma, float* dz, int64_t lddz, void* stream);
 /* last Linear(d, 1) of the discriminator (:43); when delta != NULL the same pass writes the seed
  * delta[r,j] = rowscale[r] * w[j] * slope[r,j] of the backward / input-gradient chain */
 int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,

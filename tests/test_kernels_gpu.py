@@ -517,6 +517,20 @@ def test_batchnorm_relu_forward_backward(ops):
     dz = torch.empty(B, F, device=d)
     ops.bn_relu_bwd(dy.to(d), y, zd, mean, invstd, gamma.to(d), dbeta, dgamma, B, dz)
     close(dz, gz, what='dz')
+    # the fused forms (reduction finish inside the BatchNorm kernel) are bit-identical to the two-launch ones
+    mean2, invstd2 = torch.empty(F, device=d), torch.empty(F, device=d)
+    run_m2, run_v2 = torch.zeros(F, device=d), torch.ones(F, device=d)
+    y2 = torch.full((B, F), float('nan'), device=d)
+    R = ops.colreduce_partial(0, zd, part)
+    ops.bn_relu_fwd_fused(zd, y2, part, R, B, gamma.to(d), beta.to(d), mean2, invstd2, run_mean=run_m2, run_var=run_v2)
+    assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd)
+    assert torch.equal(run_m2, run_m) and torch.equal(run_v2, run_v)
+    dbeta2, dgamma2 = torch.empty(F, device=d), torch.empty(F, device=d)
+    dz2 = torch.full((B, F), float('nan'), device=d)
+    R = ops.colreduce_partial(2, dy.to(d), part, y=y, z=zd, mean=mean, invstd=invstd)
+    ops.bn_relu_bwd_fused(dy.to(d), y, zd, part, R, B, mean, invstd, gamma.to(d), dbeta2, dgamma2, dz2)
+    assert torch.equal(dbeta2, dbeta) and torch.equal(dgamma2, dgamma)
+    close(dz2, dz, rtol=1e-6, what='fused dz')        # same formula; FMA contraction may differ between the kernels
 
 
 # ------------------------------------------------------------------------------------------------
