@@ -277,6 +277,7 @@ class StepEngine(object):
         self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
         self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
+        self._g1_issued = False  # W1 W1^T of this discriminator update is already on its way (_draw_inputs)
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
         self.pair_forwards = True    # data-parallel train_step: one BatchNorm all-reduce per layer for both forwards
@@ -452,6 +453,12 @@ class StepEngine(object):
                 ops.row_select(s.bitmaps, c.sel, c.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
                                rng=self.rng, cntblk=s.cntblk, site=ops.SITE_ROWPICK + self._so)
                 ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=C)
+            if self.gp_gram:
+                # W1 W1^T of the Gram-form penalty (see _d_back): issued here, beside the generator forward's
+                # chain of small kernels, rather than beside the discriminator's first-layer product
+                W1 = self.disc.P('seq.0.weight')
+                ops.gemm(W1, W1, self.G1, trans_b=True)
+                self._g1_issued = True
 
     def _gen_weight(self, l):
         return self.gen.P('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
@@ -692,8 +699,10 @@ class StepEngine(object):
             #   penalty part of dW1 = u^T v0 = (u^T diag(f) u) W1
             # so neither xhat, g0 = u W1 nor v0 (each [n, K0]) is formed, and the K0-wide products
             # shrink from 3n to 2n rows (forward, weight gradient) or disappear (g0, v1).
-            with self._fork(0):
-                ops.gemm(W1, W1, self.G1, trans_b=True)        # beside the forward
+            if not self._g1_issued:
+                with self._fork(0):
+                    ops.gemm(W1, W1, self.G1, trans_b=True)
+            self._g1_issued = False
             self._disc_forward_stacked(inj)
         else:
             ops.interpolate(self.Xd[B:2 * B], self.Xd[0:B], self.Xd[2 * B:3 * B], n, self.K0, alpha_inj=inj.get('alpha'),
@@ -825,10 +834,13 @@ class StepEngine(object):
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
-        with self._fork(0) as part:
-            self._gen_dweight(c, L, self.dfake, part)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
+        # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
+        # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
+        # would take twice as long; from here on it runs beside that chain's small kernels
+        with self._fork(0) as part:
+            self._gen_dweight(c, L, self.dfake, part)
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
@@ -839,11 +851,11 @@ class StepEngine(object):
             ops.bn_relu_bwd_fused(dy, yv, c.Z[l], self.part, R, count, c.bn_mean[l], c.bn_invstd[l],
                                   g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l])
             Wl = g.P('seq.%d.fc.weight' % l)
-            with self._fork((L - l) % 2) as part:
-                self._gen_dweight(c, l, self.dZ[l], part)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
                 ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
+            with self._fork((L - l) % 2) as part:               # after the chain's product, as above
+                self._gen_dweight(c, l, self.dZ[l], part)
         self._join()
         if self.sparse_cond and not ops.DETERMINISTIC:
             # the scattered cond-column gradients into their places in the flat gradient buffer
