@@ -177,6 +177,7 @@ struct GramAllArgs {
   // products follow from the first layer's plain products zpre = x W1^T [2n, d] without forming it:
   //   fake_i . v0_i = f_i * (u_i . zpre_i),  real_i . v0_i = f_i * (u_i . zpre_{n+i}),  v0_i . v0_i = f_i^2 q_i
   const float* zpre; int64_t ldz; const float* gp_f; const double* gp_q; float* fc_out;
+  float* zero;     // == zpre when its rows are to be cleared once read (the next step's split-K product adds into them)
 };
 
 __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) {
@@ -196,6 +197,12 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
         else gram2_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], a.K[l], g[6], g[7], g[9]);
         dot2_partial(dl + (2 * a.n + i) * a.ldd[l], a.zpre + i * a.ldz, a.zpre + (a.n + i) * a.ldz, a.d[l], g[8], g[10]);
         g[11] = 0.f;
+        if (a.zero) {
+          for (int j = threadIdx.x; j < a.d[l]; j += blockDim.x) {      // the elements this thread just read
+            a.zero[i * a.ldz + j] = 0.f;
+            a.zero[(a.n + i) * a.ldz + j] = 0.f;
+          }
+        }
       } else if (a.vec_a[l]) gram3_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
       else gram3_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
       double s[12];
@@ -242,8 +249,8 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
 static int persample_clip_all_impl(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
                                    const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
                                    float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
-                                   float* norm_out, const float* zpre, int64_t ldz, const float* gp_f,
-                                   const double* gp_q, float* fc_out, void* stream) {
+                                   float* norm_out, float* zpre, int64_t ldz, const float* gp_f,
+                                   const double* gp_q, float* fc_out, int clear_zpre, void* stream) {
   DPC_CHECK_ARG(nlayers >= 1 && nlayers <= DPC_MAX_LAYERS, "persample_clip_all: 1..8 layers");
   DPC_CHECK_ARG(delta && ldd && d && act && lda && K && norm2 && rowc && n > 0, "persample_clip_all: null pointer");
   DPC_CHECK_ARG(!fc_out || gp_f, "persample_clip_all: fc_out needs gp_f");
@@ -258,7 +265,7 @@ static int persample_clip_all_impl(int nlayers, const float* const* delta, const
   }
   a.nlayers = nlayers; a.n = n; a.clip = clip; a.gscale = gscale; a.norm2 = norm2; a.rowc = rowc; a.roww = roww;
   a.rowc_w = rowc_w; a.norm_out = norm_out;
-  a.zpre = zpre; a.ldz = ldz; a.gp_f = gp_f; a.gp_q = gp_q; a.fc_out = fc_out;
+  a.zpre = zpre; a.ldz = ldz; a.gp_f = gp_f; a.gp_q = gp_q; a.fc_out = fc_out; a.zero = clear_zpre ? zpre : nullptr;
   hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(256), 0,
                      (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
@@ -270,7 +277,7 @@ extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, co
                                       float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
                                       float* norm_out, void* stream) {
   return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
-                                 norm_out, nullptr, 0, nullptr, nullptr, nullptr, stream);
+                                 norm_out, nullptr, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // The same with the penalty row of layer 0 left implicit (see GramAllArgs): act[0] is [2n, K[0]] (fake and
@@ -280,12 +287,13 @@ extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, co
 extern "C" int dpc_persample_clip_all_gram(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
                                            const float* const* act, const int64_t* lda, const int* K, int64_t n,
                                            float clip, float gscale, double* norm2, float* rowc, const float* roww,
-                                           float* rowc_w, float* norm_out, const float* zpre, int64_t ldz,
-                                           const float* gp_f, const double* gp_q, float* fc_out, void* stream) {
+                                           float* rowc_w, float* norm_out, float* zpre, int64_t ldz,
+                                           const float* gp_f, const double* gp_q, float* fc_out, int clear_zpre,
+                                           void* stream) {
   DPC_CHECK_ARG(zpre && gp_f && gp_q, "persample_clip_all_gram: null pointer");
   DPC_CHECK_ARG(nlayers >= 1 && d && ldz >= d[0], "persample_clip_all_gram: ldz < d[0]");
   return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
-                                 norm_out, zpre, ldz, gp_f, gp_q, fc_out, stream);
+                                 norm_out, zpre, ldz, gp_f, gp_q, fc_out, clear_zpre, stream);
 }
 
 // c_i = min(1, clip / (gscale * sqrt(norm2[i]))); rowc[p*n + i] = c_i for the three rows of example i

@@ -551,6 +551,8 @@ struct FirstActArgs {
   const float* alpha_inj; const uint8_t* keep; int64_t ld_keep;
   const uint64_t* rng; uint32_t site_alpha, site_keep; float leak;
   float* H; int64_t ldh; float* S; int64_t lds; float* alpha_out;
+  int stacked;      // 1: zpre [2n, d] -> 3n stacked rows (above); 0: zpre [n, d] -> n rows, no interpolates
+  float* zero;      // == zpre (mutable) when the products are to be cleared once read (see the entry point)
 };
 
 template <bool VEC>
@@ -561,23 +563,36 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / per_row;
     const int j = (int)(i - r * per_row) * W;
-    const float al = a.alpha_inj ? a.alpha_inj[r] : dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site_alpha, (uint64_t)r));
-    if (a.alpha_out && j == 0) a.alpha_out[r] = al;
+    float al = 0.f;
+    if (a.stacked) {
+      al = a.alpha_inj ? a.alpha_inj[r] : dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site_alpha, (uint64_t)r));
+      if (a.alpha_out && j == 0) a.alpha_out[r] = al;
+    }
     float zf[W], zr[W], b[W];
     if constexpr (VEC) {
       const float4 f4 = *reinterpret_cast<const float4*>(a.zpre + r * a.ldz + j);
-      const float4 r4 = *reinterpret_cast<const float4*>(a.zpre + (a.n + r) * a.ldz + j);
+      const float4 r4 = a.stacked ? *reinterpret_cast<const float4*>(a.zpre + (a.n + r) * a.ldz + j) : f4;
       const float4 b4 = *reinterpret_cast<const float4*>(a.bias + j);
+      if (a.zero) {
+        *reinterpret_cast<float4*>(a.zero + r * a.ldz + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.stacked) *reinterpret_cast<float4*>(a.zero + (a.n + r) * a.ldz + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       zf[0] = f4.x; zf[1] = f4.y; zf[2] = f4.z; zf[3] = f4.w;
       zr[0] = r4.x; zr[1] = r4.y; zr[2] = r4.z; zr[3] = r4.w;
       b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
     } else {
       zf[0] = a.zpre[r * a.ldz + j];
-      zr[0] = a.zpre[(a.n + r) * a.ldz + j];
+      zr[0] = a.stacked ? a.zpre[(a.n + r) * a.ldz + j] : 0.f;
       b[0] = a.bias[j];
+      if (a.zero) {
+        a.zero[r * a.ldz + j] = 0.f;
+        if (a.stacked) a.zero[(a.n + r) * a.ldz + j] = 0.f;
+      }
     }
+    const int np = a.stacked ? 3 : 1;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
+      if (p >= np) break;
       const int64_t row = (int64_t)p * a.n + r;
       uint32_t bits[W];
       if (a.keep) {
@@ -608,18 +623,19 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
   }
 }
 
-extern "C" int dpc_disc_first_layer_act(const float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
+extern "C" int dpc_disc_first_layer_act(float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
                                         const float* alpha_inj, const uint8_t* keep, int64_t ld_keep,
                                         const uint64_t* rng, uint32_t site_alpha, uint32_t site_keep, float leak,
-                                        float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, void* stream) {
+                                        float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, int stacked,
+                                        int clear_zpre, void* stream) {
   DPC_CHECK_ARG(zpre && bias && H && S && n > 0 && d > 0, "disc_first_layer_act: bad argument");
   DPC_CHECK_ARG(ldz >= d && ldh >= d && lds >= d, "disc_first_layer_act: leading dimension < d");
-  DPC_CHECK_ARG((alpha_inj && keep) || rng, "disc_first_layer_act: no random source");
+  DPC_CHECK_ARG(((alpha_inj || !stacked) && keep) || rng, "disc_first_layer_act: no random source");
   DPC_CHECK_ARG(!keep || ld_keep >= d, "disc_first_layer_act: ld_keep < d");
   FirstActArgs a;
   a.zpre = zpre; a.ldz = ldz; a.bias = bias; a.n = n; a.d = d; a.alpha_inj = alpha_inj; a.keep = keep; a.ld_keep = ld_keep;
   a.rng = rng; a.site_alpha = site_alpha; a.site_keep = site_keep; a.leak = leak; a.H = H; a.ldh = ldh; a.S = S; a.lds = lds;
-  a.alpha_out = alpha_out;
+  a.alpha_out = alpha_out; a.stacked = stacked ? 1 : 0; a.zero = clear_zpre ? zpre : nullptr;
   const bool vec = (d % 4 == 0) && (ldz % 4 == 0) && (ldh % 4 == 0) && (lds % 4 == 0) &&
                    ((((uintptr_t)zpre | (uintptr_t)bias | (uintptr_t)H | (uintptr_t)S) & 15) == 0);
   if (vec)

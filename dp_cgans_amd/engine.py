@@ -567,7 +567,18 @@ class StepEngine(object):
         rs = slice(row0, row0 + rows)
         x = self.Xd3[rs] if X3 is None else X3
         keeps = inj.get('keep')
-        for i in range(M):
+        first = 0
+        if X3 is not None and rows <= 2 * self.n:
+            # K0-long first product into the all-zero Zp (see _disc_forward_stacked: no memset node), then
+            # bias + LeakyReLU + Dropout in the pass that clears Zp again
+            zp = self.Zp[0:rows]
+            ops.gemm(x, d.P('seq.0.weight'), zp, trans_b=True, beta=1.0)
+            ops.disc_first_layer_act(zp, d.P('seq.0.bias'), rows, self.H[0][rs], self.S[0][rs],
+                                     keep=keeps[0] if keeps else None, rng=self.rng, site_keep=ops.SITE_DROP0 + self._so,
+                                     leak=LEAK, stacked=False, clear=True)
+            x = self.H[0][rs]
+            first = 1
+        for i in range(first, M):
             ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
                      rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
@@ -585,11 +596,14 @@ class StepEngine(object):
         products are taken for the fake and real rows only, and those of xhat = a*real + (1-a)*fake follow
         by linearity inside the activation pass; the other layers run over all 3n rows as usual."""
         d, M, n = self.disc, self.M, self.n
-        ops.gemm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True)
+        # Zp is all zero here (allocated so; its last reader - the activation pass, or the per-example Gram
+        # kernel in DP-SGD mode - clears what it reads): the K0-long product
+        # runs split-K with its atomics adding straight into it, no memset node in front
+        ops.gemm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True, beta=1.0)
         keeps = inj.get('keep')
         ops.disc_first_layer_act(self.Zp, d.P('seq.0.bias'), n, self.H[0], self.S[0], alpha_inj=inj.get('alpha'),
                                  keep=keeps[0] if keeps else None, rng=self.rng, site_alpha=ops.SITE_ALPHA + self._so,
-                                 site_keep=ops.SITE_DROP0 + self._so, leak=LEAK)
+                                 site_keep=ops.SITE_DROP0 + self._so, leak=LEAK, clear=self.dp_mode != 'dpsgd')
         x = self.H[0]
         for i in range(1, M):
             ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
@@ -739,7 +753,7 @@ class StepEngine(object):
             if gram:
                 ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
                                        roww=self.rowscale_d, rowc_w=self.rowc_w, norm_out=self.norms, zpre=self.Zp,
-                                       gp_f=self.gp_f, gp_q=self.gp_q, fc_out=self.gp_fc)
+                                       gp_f=self.gp_f, gp_q=self.gp_q, fc_out=self.gp_fc, clear_zpre=True)
                 pen_scale = self.gp_fc
             else:
                 ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,

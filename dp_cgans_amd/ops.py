@@ -364,17 +364,19 @@ def gp_norm(g0, coef, pen_rows, nrm_out=None):
 
 
 def disc_first_layer_act(zpre, bias, n, H, S, alpha_inj=None, keep=None, rng=None, site_alpha=SITE_ALPHA,
-                         site_keep=SITE_DROP0, leak=0.2, alpha_out=None):
-    """H, S [3n, d] of the stacked rows [fake | real | interpolates] from zpre [2n, d] = x W1^T."""
+                         site_keep=SITE_DROP0, leak=0.2, alpha_out=None, stacked=True, clear=False):
+    """H, S [3n, d] of the stacked rows [fake | real | interpolates] from zpre [2n, d] = x W1^T; not
+    ``stacked``: H, S [n, d] from zpre [n, d].  ``clear``: zpre is zeroed once read."""
     _chk(keep, torch.uint8, 'keep')
     d = zpre.shape[1]
-    if zpre.shape[0] != 2 * n or H.shape[0] != 3 * n or S.shape[0] != 3 * n or H.shape[1] != d or S.shape[1] != d:
-        raise ValueError('disc_first_layer_act: zpre needs 2n rows, H and S 3n rows of the same width')
-    if keep is not None and (keep.shape[0] != 3 * n or keep.shape[1] != d):
-        raise ValueError('disc_first_layer_act: keep must be [3n, d]')
+    zi, zo = (2, 3) if stacked else (1, 1)
+    if zpre.shape[0] != zi * n or H.shape[0] != zo * n or S.shape[0] != zo * n or H.shape[1] != d or S.shape[1] != d:
+        raise ValueError('disc_first_layer_act: zpre needs %dn rows, H and S %dn rows of the same width' % (zi, zo))
+    if keep is not None and (keep.shape[0] != zo * n or keep.shape[1] != d):
+        raise ValueError('disc_first_layer_act: keep must be [%dn, d]' % zo)
     lib().call('dpc_disc_first_layer_act', _p(zpre), _ld(zpre), _p(bias), n, d, _p(alpha_inj), _p(keep),
                _ld(keep) if keep is not None else 0, _p(rng), site_alpha, site_keep, leak, _p(H), _ld(H), _p(S), _ld(S),
-               _p(alpha_out), _stream())
+               _p(alpha_out), int(bool(stacked)), int(bool(clear)), _stream())
 
 
 def gp_gram_rows(T, u, slope, coef, pen_rows, f_out, v1, q_out=None, nrm_out=None):
@@ -430,7 +432,7 @@ def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK, t_add=1):
 
 
 def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=None, norm_out=None, zpre=None,
-                       gp_f=None, gp_q=None, fc_out=None):
+                       gp_f=None, gp_q=None, fc_out=None, clear_zpre=False):
     """layers: [(delta [3n,d], act [3n,K])]; all Gram contractions and the clip factors in one launch.
     With ``zpre`` the penalty row of layer 0's act is implicit (act[0] needs only its first 2n rows):
     see dpc_persample_clip_all_gram."""
@@ -455,7 +457,8 @@ def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=N
     else:
         if zpre.shape[0] != 2 * n or zpre.shape[1] != layers[0][0].shape[1]:
             raise ValueError('persample_clip_all: zpre must be [2n, d0]')
-        lib().call('dpc_persample_clip_all_gram', *args, _p(zpre), _ld(zpre), _p(gp_f), _p(gp_q), _p(fc_out), _stream())
+        lib().call('dpc_persample_clip_all_gram', *args, _p(zpre), _ld(zpre), _p(gp_f), _p(gp_q), _p(fc_out),
+                   int(bool(clear_zpre)), _stream())
 
 
 def condvec_original(table, cond_st, dims, matrix_st, cond, rows_inj=None, cols_inj=None, rng=None, site=SITE_CONDVEC):

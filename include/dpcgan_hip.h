@@ -271,12 +271,14 @@ int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef, double* pe
  * [2n, d] = plain products of the fake rows then the real rows (dpc_gemm_f32, no bias); writes
  * H = pre*slope and S = slope = (pre > 0 ? 1 : leak)*keep*2 for all 3n rows, the arithmetic of
  * dpc_gemm_f32's epilogue 1 (keep u8 [3n, d] or Philox draw row*d + col of site_keep; alpha_inj [n]
- * or Philox draw r of site_alpha, as dpc_interpolate). */
-int dpc_disc_first_layer_act(const float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
+ * or Philox draw r of site_alpha, as dpc_interpolate).  stacked == 0: zpre [n, d] -> H, S [n, d], the
+ * plain Linear + LeakyReLU + Dropout of n rows.  clear_zpre != 0: every product is set to 0 once read,
+ * so that the next split-K product can add into the buffer without a memset in front of it. */
+int dpc_disc_first_layer_act(float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
                              const float* alpha_inj, const uint8_t* keep, int64_t ld_keep,
                              const uint64_t* rng, uint32_t site_alpha, uint32_t site_keep, float leak,
-                             float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out,
-                             void* stream);
+                             float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, int stacked,
+                             int clear_zpre, void* stream);
 /* calc_gradient_penalty (:55-62) through the first layer's Gram matrix G = W1 W1^T: with u [n, d] the
  * penalty rows of the first layer's backward delta and T = u G,  ||grad_xhat D||^2 = rowsum(T*u)
  * and the penalty rows of the next v-chain link are v1 = f*T*slope, f = coef*(nrm-1)/nrm.  Writes
@@ -318,12 +320,13 @@ int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t
  * (dpc_gp_gram_rows): act[0] is [2n, K[0]] (fake and real rows only), zpre [2n, d[0]] the first
  * layer's plain products x W1^T, gp_f / gp_q the outputs of dpc_gp_gram_rows; the Gram entries of the
  * missing row are f_i*(u_i . zpre_i), f_i*(u_i . zpre_{n+i}) and f_i^2 * q_i.  fc_out[i] (nullable)
- * = c_i * gp_f[i]. */
+ * = c_i * gp_f[i].  clear_zpre != 0: zpre is set to 0 once read (see dpc_disc_first_layer_act). */
 int dpc_persample_clip_all_gram(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
                                 const float* const* act, const int64_t* lda, const int* K, int64_t n,
                                 float clip, float gscale, double* norm2, float* rowc, const float* roww,
-                                float* rowc_w, float* norm_out, const float* zpre, int64_t ldz,
-                                const float* gp_f, const double* gp_q, float* fc_out, void* stream);
+                                float* rowc_w, float* norm_out, float* zpre, int64_t ldz,
+                                const float* gp_f, const double* gp_q, float* fc_out, int clear_zpre,
+                                void* stream);
 /* c_i = min(1, clip / (gscale*sqrt(norm2[i]))) -> rowc[p*n+i] (p = 0..2), rowc_w = rowc * roww
  * (nullable), norm_out[i] = gscale*sqrt(norm2[i]) (nullable). */
 int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,

@@ -608,6 +608,12 @@ def test_first_layer_act_equals_interpolate_then_linear(ops, n, d, K0):
         assert torch.equal(S.cpu()[sure], S_ref.cpu()[sure])
         assert sure.float().mean() > 0.99
         close(H.cpu()[sure], H_ref.cpu()[sure], what='first layer H (inj %s)' % inj)
+        # n plain rows (no interpolates), products cleared once read
+        Z1 = Zp[0:n].clone()
+        H1, S1 = torch.full((n, d), float('nan'), device=d_), torch.full((n, d), float('nan'), device=d_)
+        ops.disc_first_layer_act(Z1, b, n, H1, S1, keep=keep[0:n] if inj else None, rng=rng, site_keep=ops.SITE_DROP0,
+                                 leak=0.2, stacked=False, clear=True)
+        assert torch.equal(H1, H[0:n]) and torch.equal(S1, S[0:n]) and float(Z1.abs().max()) == 0.0
         keep_bits = (S.cpu() != 0)
         if inj:
             assert torch.equal(keep_bits, keep.cpu().bool())
