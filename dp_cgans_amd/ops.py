@@ -18,7 +18,8 @@ SITE_NOISE_D, SITE_HOOK, SITE_ENCODE = 7, 8, 9
 
 
 # When set to a list, gemm() brackets every launch with HIP events on the launch stream and appends
-# (start_event, end_event, flops, tag); bench.py uses it for the live roofline measurement.
+# (start_event, end_event, flops, tag, replay) - replay() issues the identical launch again; bench.py
+# uses it for the live roofline measurement.
 GEMM_PROFILE = None
 
 
@@ -103,13 +104,14 @@ def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
-               epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
-               _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
-               site, leak, splitk, _p(kscale), _stream())
+    args = ('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
+            epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
+            _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
+            site, leak, splitk, _p(kscale))
+    lib().call(*args, _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b)))
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b), lambda: lib().call(*args, _stream())))
     return C
 
 
@@ -131,11 +133,12 @@ def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call('dpc_gemm_f32_gather', M, N, K, 1.0, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, _p(C), _ld(C), _p(bias), epi,
-               _p(gat), _ld(gat), _p(gidx), _stream())
+    args = ('dpc_gemm_f32_gather', M, N, K, 1.0, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, _p(C), _ld(C), _p(bias), epi,
+            _p(gat), _ld(gat), _p(gidx))
+    lib().call(*args, _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, False, trans_b)))
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, False, trans_b), lambda: lib().call(*args, _stream())))
     return C
 
 

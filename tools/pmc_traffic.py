@@ -4,7 +4,8 @@ of `python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-g
 
 Units / corrections as MI355X_MICROARCH.md (HBM) prescribes: both counters are in KiB; on gfx950
 FETCH_SIZE reports half the bytes of 16-byte-per-lane coalesced reads (calibrated here on
-interpolate_kernel, which reads exactly 2 x 4 x n x group_len bytes), so it is doubled; WRITE_SIZE is
+activate_fwd_kernel, which reads the generator's raw output once: 4 x B x Dd bytes; earlier rounds used
+interpolate_kernel, which the Gram-form penalty no longer launches), so it is doubled; WRITE_SIZE is
 exact.  Writes profiles/<tag>_gemm_traffic.json, which bench.py reports as roofline.traffic.
 
 usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
@@ -27,14 +28,14 @@ def main():
     is_gemm = lambda k: 'gemm_f32_kernel' in k or 'gemm_streamk_kernel' in k     # one of the two per GEMM call
     gf = [v for k, vs in F.items() if is_gemm(k) for v in vs]
     gw = [v for k, vs in W.items() if is_gemm(k) for v in vs]
-    cal = [v for k, vs in F.items() if 'interpolate_kernel' in k for v in vs]
+    cal = [v for k, vs in F.items() if 'activate_fwd_kernel' in k for v in vs]
     out = {
         'kernel': 'gemm_f32_kernel + gemm_streamk_kernel', 'launches': len(gf),
         'fetch_size_kib_avg': sum(gf) / len(gf), 'write_size_kib_avg': sum(gw) / len(gw),
         'fetch_correction': 2.0,
         'traffic_bytes_per_launch': (2.0 * sum(gf) / len(gf) + sum(gw) / len(gw)) * 1024.0,
-        'calibration': {'kernel': 'interpolate_kernel', 'fetch_size_kib_avg': sum(cal) / len(cal) if cal else None,
-                        'expected_read_bytes': 2 * 4 * 1024 * 4888},
+        'calibration': {'kernel': 'activate_fwd_kernel', 'fetch_size_kib_avg': sum(cal) / len(cal) if cal else None,
+                        'expected_read_bytes': 4 * 8192 * 335},
         'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 3 --warmup 2 '
                    '--no-cpu-baseline --no-roofline --no-graph',
     }
