@@ -38,6 +38,7 @@ def main():
                     help="private=True semantics: north_star DP-SGD (per-example clip + Gaussian noise) or the "
                          "reference's grad-hook noise + weight clamp")
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
+    ap.add_argument('--serial', action='store_true', help='no side streams: the step is one chain of kernels (tuning)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -66,6 +67,8 @@ def main():
     eng = StepEngine(span, 128, dims, dims, args.batch, args.pac, dev, private=True, seed=0, dist=dist,
                      dp_mode=args.dp_mode, dp_sigma=1.0, dp_clip=1.0)
     eng.sampler = sampler
+    if args.serial:
+        eng.concurrent = False
     torch.cuda.synchronize()
     setup_s = time.time() - t0
 
