@@ -835,7 +835,6 @@ class StepEngine(object):
         self._k = 0
         self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
-        self._join()
         self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3)
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
@@ -850,6 +849,7 @@ class StepEngine(object):
         WL = g.P('seq.%d.weight' % L)
         if hid > 0:
             ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
+        self._join()     # branches still open from the front half (the hot-id sort, deferred running statistics)
         # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
         # would take twice as long; from here on it runs beside that chain's small kernels
