@@ -110,3 +110,42 @@ def test_training_steps_at_full_size(t1m, mode):
         assert float(eng.disc.g.double().norm()) <= clip * (1 + 1e-4)
     else:
         assert float(eng.disc.p.abs().max()) <= 0.01 + 1e-9           # weight clamp
+
+
+@pytest.mark.parametrize('mode', ['dpsgd', 'reference'])
+def test_both_forms_of_the_step_agree_at_full_size(t1m, mode):
+    """The step's two algebraic shortcuts at BASELINE's size: the Gram-form gradient penalty (no [n, K0]
+    operand formed) and the two-hot cond columns as row gathers / row sums, against the direct form (the
+    reference's op sequence: interpolates, g0 = u W1, dense cond columns) on the SAME Philox draws.
+    Losses, per-example norms, discriminator and generator gradients within the step's 2e-5 bar."""
+    from dp_cgans_amd.engine import StepEngine
+    table, span, s = t1m
+
+    def run(**kw):
+        eng = StepEngine(span, 128, (256, 256), (256, 256), 8192, 8, DEV, private=True, dp_mode=mode, dp_clip=0.05,
+                         seed=11, **kw)
+        eng.sampler = s
+        eng.d_step(update=False)
+        dg = eng.disc.g.clone()
+        norms = eng.norms.clone()
+        eng.g_step(update=False)
+        torch.cuda.synchronize()
+        return eng, dg, norms, eng.gen.g.clone(), eng.losses.clone()
+    a, dga, na, gga, la = run()
+    b, dgb, nb, ggb, lb = run(gp_gram=False, sparse_cond=False)
+    assert a.gp_gram and a.sparse_cond and not b.gp_gram and not b.sparse_cond
+    assert torch.equal(a.row_id, b.row_id) and torch.equal(a.cg.sel, b.cg.sel)       # same draws
+
+    def close(x, y, what, rtol=2e-5):
+        err = float((x.double() - y.double()).abs().max()) / max(float(y.double().abs().max()), 1e-30)
+        assert err <= rtol, '%s: %.3e' % (what, err)
+    close(la, lb, 'losses')
+    for k in a.disc.keys:
+        close(a.disc.view(dga, k), b.disc.view(dgb, k), 'D grad ' + k)
+    for k in a.gen.keys:
+        if 'fc.bias' in k:        # exactly-zero gradient in front of BatchNorm: rounding noise on both sides
+            continue
+        close(a.gen.view(gga, k), b.gen.view(ggb, k), 'G grad ' + k)
+    if mode == 'dpsgd':
+        close(na, nb, 'per-example norms')
+        assert float(a.rowc.min()) < 1.0

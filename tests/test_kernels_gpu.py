@@ -446,6 +446,16 @@ def test_gather_gemm_equals_dense_linear_over_hot_columns(ops, B, C, F, Kd):
         out = torch.full((B, F), float('nan'), device=d_)
         ops.gemm_gather(inp[:, :Kd], Wd[:, :Kd], out, WcT, sel, bias=b.to(d_), epi=epi)
         close(out, torch.relu(ref) if epi else ref, what='gather gemm epi %d' % epi)
+    # every block tile (the 64x64 one prefetches the gathered rows before its K loop, the others stage them after it)
+    from dp_cgans_amd._lib import lib
+    try:
+        for tile in (64, 128, 12864, 64128):
+            lib().call('dpc_gemm_config', tile)
+            out = torch.full((B, F), float('nan'), device=d_)
+            ops.gemm_gather(inp[:, :Kd], Wd[:, :Kd], out, WcT, sel, bias=b.to(d_))
+            close(out, ref, what='gather gemm tile %d' % tile)
+    finally:
+        lib().call('dpc_gemm_config', 0)
     # rows that are not one-/two-hot are counted
     inp[3, Kd:Kd + 3] = 1
     inp[5, Kd] = 0.5
