@@ -20,6 +20,7 @@ Memory layout (all fp32, row-major, resident in HBM for the whole fit):
                                   and real rows, and W1 W1^T; the interpolates and the K0-wide penalty
                                   gradient are then never formed (third block of Xd unused)
 """
+import contextlib
 import math
 
 import numpy as np
@@ -278,6 +279,8 @@ class StepEngine(object):
         self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
         self._g1_issued = False  # W1 W1^T of this discriminator update is already on its way (_draw_inputs)
+        self._pair_R = {}        # row chunks of the paired forwards' column reductions, per layer
+        self._early_open = False # the early stream holds work of _gen_forward_pair the main stream has not joined
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
         self.pair_forwards = True    # data-parallel train_step: one BatchNorm all-reduce per layer for both forwards
@@ -511,30 +514,81 @@ class StepEngine(object):
             self.bn_batches += 1
         self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
 
-    def _gen_forward_pair(self, ca, cb):
+    def _gen_forward_pair(self, ca, cb, so_a, so_b):
         """Two generator forwards in lockstep (the last discriminator update's and the generator
-        update's: same weights, different inputs) for data-parallel steps: the BatchNorm column sums of
-        both go into ONE buffer and ONE all-reduce per layer instead of two.  Same arithmetic and the
-        same running-statistics order (ca then cb) as two _gen_forward calls."""
+        update's: same weights, different inputs) for data-parallel steps, activations included: the
+        BatchNorm column sums of both go into ONE buffer and ONE all-reduce per layer instead of two.
+        Same arithmetic and the same running-statistics order (ca then cb) as two _gen_forward calls.
+        The two are independent chains of small kernels, so cb's runs on the `early` stream beside ca's
+        (joined at every collective); cb's last Linear and activation are left running there when this
+        returns - ``_join_early`` (called by the next collective and before the generator update's
+        backward) brings them back."""
         g = self.gen
         count = float(self.gB)
+        main = torch.cuda.current_stream(self.dev)
+        lanes = self.concurrent and self.early is not None
+        if self.sparse_cond and (self._wct_stale or self.gen.loaded):
+            self.gen.loaded = False
+            self._refresh_wct()
+
+        class lane_b(object):          # ``with lane_b():`` issues on the early stream, after what that stream holds
+            def __enter__(s_):
+                s_.ctx = torch.cuda.stream(self.early) if lanes else None
+                if s_.ctx is not None:
+                    s_.ctx.__enter__()
+
+            def __exit__(s_, *a):
+                if s_.ctx is not None:
+                    s_.ctx.__exit__(*a)
+                return False
+        if lanes:
+            self.early.wait_stream(main)            # cb's inputs were drawn on the main stream
         for l in range(self.L):
             F = self.gdim[l]
             b = g.P('seq.%d.fc.bias' % l)
-            R = 0
-            for i, c in enumerate((ca, cb)):          # same shape, hence the same R: the two sets lie back to back
-                self._gen_linear(c, l, c.Z[l], b)
-                R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
+            Rc = self._pair_R.get(l)
+            if Rc is None or not lanes:
+                # first call (R, the number of row chunks of the reduction, is not known yet): one after the other
+                R = 0
+                for i, c in enumerate((ca, cb)):      # same shape, hence the same R: the two sets lie back to back
+                    self._gen_linear(c, l, c.Z[l], b)
+                    R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
+                self._pair_R[l] = R
+                if lanes:
+                    self.early.wait_stream(main)
+            else:
+                R = Rc
+                with lane_b():
+                    self._gen_linear(cb, l, cb.Z[l], b)
+                    Rb = ops.colreduce_partial(0, cb.Z[l], self.pair_part[R * 2 * F:])
+                self._gen_linear(ca, l, ca.Z[l], b)
+                Ra = ops.colreduce_partial(0, ca.Z[l], self.pair_part)
+                assert Ra == R and Rb == R
+                main.wait_stream(self.early)
             self._allreduce(self.pair_part[:2 * R * 2 * F])
             for i, c in enumerate((ca, cb)):
-                ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]],
-                                      self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, count,
-                                      g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l], c.bn_invstd[l],
-                                      run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
-                                      run_var=self.bn_run['seq.%d.bn.running_var' % l])
+                if i == 1 and lanes:
+                    self.early.wait_stream(main)     # after ca's: the running statistics are updated in sequence order
+                with (lane_b() if i == 1 else contextlib.nullcontext()):
+                    ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]],
+                                          self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, count,
+                                          g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l],
+                                          c.bn_invstd[l], run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
+                                          run_var=self.bn_run['seq.%d.bn.running_var' % l])
         self.bn_batches += 2
-        for c in (ca, cb):
-            self._gen_linear(c, self.L, c.fake, g.P('seq.%d.bias' % self.L))
+        with lane_b():
+            self._so = so_b
+            self._gen_linear(cb, self.L, cb.fake, g.P('seq.%d.bias' % self.L))
+            self._activate({}, cb)
+        self._so = so_a
+        self._gen_linear(ca, self.L, ca.fake, g.P('seq.%d.bias' % self.L))
+        self._activate({}, ca, raw=True)
+        self._early_open = lanes
+
+    def _join_early(self):
+        if self._early_open:
+            torch.cuda.current_stream(self.dev).wait_stream(self.early)
+            self._early_open = False
 
     def _bn_running(self, c):
         """The running-statistics update a ``_gen_forward(c, running=False)`` left out, in its place in
@@ -672,6 +726,7 @@ class StepEngine(object):
         if not self.dist.active:
             return t
         self._join()             # a collective (and a graph cut) needs every branch back on the main stream
+        self._join_early()
         if self._ar_hook is not None:      # graph capture in progress: the collective runs between graph segments
             self._ar_hook(t)
             return t
@@ -908,13 +963,11 @@ class StepEngine(object):
             self._gen_gx.zero_()
             self._draw_inputs({}, need_real=False, c=self.cg)
             if self.sparse_cond:
-                ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
-            self._gen_forward_pair(self.cd, self.cg)
-            self._so = 64 * last
-            self._activate({}, self.cd, raw=True)
-            self._so = 64 * d_steps
-            self._activate({}, self.cg)
+                with self._fork(1):      # joined by the first collective; the generator backward reads it
+                    ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
+            self._gen_forward_pair(self.cd, self.cg, 64 * last, 64 * d_steps)
             self._d_back({}, True, last)
+            self._join_early()
             self._g_back({}, True, d_steps)
             ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
             return
