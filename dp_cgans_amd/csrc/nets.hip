@@ -310,6 +310,7 @@ struct BnBwdFusedArgs {
   const float* mean; const float* invstd; const float* gamma;
   float* dbeta; float* dgamma; float* dz; int64_t lddz;
   int64_t rows_per_block;
+  float out_scale;     // dbeta / dgamma are written times this (1/world: they are global sums already, see the entry point)
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(BnBwdFusedArgs a) {
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(BnBwdFusedArgs a
   if (f >= a.F) return;
   const float db = (float)s0, dg = (float)s1;
   if (blockIdx.y == 0 && rl == 0) {
-    a.dbeta[f] = db;
-    a.dgamma[f] = dg;
+    a.dbeta[f] = db * a.out_scale;
+    a.dgamma[f] = dg * a.out_scale;
   }
   const float mu = a.mean[f], is = a.invstd[f], ga = a.gamma[f];
   const float inv_count = (float)(1.0 / a.count);
@@ -337,16 +338,19 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(BnBwdFusedArgs a
 
 // part: the R x 2 x F partial sums of dpc_colreduce_partial mode 2 (all-reduced over ranks if any);
 // writes dbeta, dgamma (= the finished sums) and dz as dpc_colreduce_finish kind 2 + dpc_bn_relu_bwd do.
+// grad_scale multiplies the dbeta / dgamma that are WRITTEN (dz uses the unscaled sums): a data-parallel
+// caller passes 1/world, because the sums are global already and the flat gradient buffer they land in
+// is summed over ranks afterwards.
 extern "C" int dpc_bn_relu_bwd_fused(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z,
                                      int64_t ldz, int64_t B, int F, const double* part, int R, double count,
                                      const float* mean, const float* invstd, const float* gamma, float* dbeta,
-                                     float* dgamma, float* dz, int64_t lddz, void* stream) {
+                                     float* dgamma, float* dz, int64_t lddz, float grad_scale, void* stream) {
   DPC_CHECK_ARG(dy && y && z && part && mean && invstd && gamma && dbeta && dgamma && dz, "bn_relu_bwd_fused: null pointer");
   DPC_CHECK_ARG(B > 0 && F > 0 && R >= 1 && count > 0.0, "bn_relu_bwd_fused: bad shape");
   BnBwdFusedArgs a;
   a.dy = dy; a.lddy = lddy; a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz; a.B = B; a.F = F; a.part = part; a.R = R;
   a.count = count; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.dbeta = dbeta; a.dgamma = dgamma; a.dz = dz;
-  a.lddz = lddz;
+  a.lddz = lddz; a.out_scale = grad_scale;
   const int64_t strips = dpc_cdiv(F, 64);
   int64_t chunks = dpc_cdiv(1024, strips);
   if (chunks > dpc_cdiv(B, 32)) chunks = dpc_cdiv(B, 32);

@@ -917,8 +917,11 @@ class StepEngine(object):
             R = ops.colreduce_partial(2, dy, self.part, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
             self._allreduce(self.part[:R * 2 * self.gdim[l]])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
+            # BatchNorm gradients come from all-reduced column sums, i.e. are global already: written
+            # times 1/world so that the sum over ranks of the flat gradient buffer leaves them unchanged
             ops.bn_relu_bwd_fused(dy, yv, c.Z[l], self.part, R, count, c.bn_mean[l], c.bn_invstd[l],
-                                  g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l])
+                                  g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l],
+                                  grad_scale=1.0 / self.dist.world if self.dist.active else 1.0)
             Wl = g.P('seq.%d.fc.weight' % l)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
@@ -937,12 +940,6 @@ class StepEngine(object):
 
     def _gen_update(self):
         g = self.gen
-        if self.dist.active:
-            # BatchNorm gradients were formed from all-reduced column sums, i.e. are global already:
-            # pre-divide so that the sum over ranks below leaves them unchanged
-            for l in range(self.L):
-                g.G('seq.%d.bn.weight' % l).mul_(1.0 / self.dist.world)
-                g.G('seq.%d.bn.bias' % l).mul_(1.0 / self.dist.world)
         self._allreduce(g.g)
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
         self._refresh_wct()

@@ -339,11 +339,12 @@ def bn_relu_fwd_fused(z, y, part, R, count, gamma, beta, mean_out, invstd_out, r
                eps, momentum, _p(gamma), _p(beta), _p(mean_out), _p(invstd_out), _p(run_mean), _p(run_var), _stream())
 
 
-def bn_relu_bwd_fused(dy, y, z, part, R, count, mean, invstd, gamma, dbeta, dgamma, dz):
-    """colreduce_finish (kind 2) + bn_relu_bwd in one launch."""
+def bn_relu_bwd_fused(dy, y, z, part, R, count, mean, invstd, gamma, dbeta, dgamma, dz, grad_scale=1.0):
+    """colreduce_finish (kind 2) + bn_relu_bwd in one launch; dbeta / dgamma are written times grad_scale."""
     _chk(part, torch.float64, 'part')
     lib().call('dpc_bn_relu_bwd_fused', _p(dy), _ld(dy), _p(y), _ld(y), _p(z), _ld(z), z.shape[0], z.shape[1], _p(part), R,
-               float(count), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _ld(dz), _stream())
+               float(count), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _ld(dz), float(grad_scale),
+               _stream())
 
 
 def disc_out_fwd(h, w, b, y, rowscale=None, slope=None, delta=None):

@@ -245,11 +245,12 @@ int dpc_bn_relu_fwd_fused(const float* z, int64_t ldz, float* y, int64_t ldy, in
                           const double* part, int R, double count, float eps, float momentum,
                           const float* gamma, const float* beta, float* mean_out, float* invstd_out,
                           float* run_mean, float* run_var, void* stream);
-/* Likewise for the backward: part = mode-2 sums; writes dbeta, dgamma and dz. */
+/* Likewise for the backward: part = mode-2 sums; writes dbeta, dgamma and dz.  grad_scale multiplies
+ * the dbeta / dgamma written (not the ones dz uses): 1/world when a sum over ranks follows. */
 int dpc_bn_relu_bwd_fused(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* z,
                           int64_t ldz, int64_t B, int F, const double* part, int R, double count,
                           const float* mean, const float* invstd, const float* gamma, float* dbeta,
-                          float* dgamma, float* dz, int64_t lddz, void* stream);
+                          float* dgamma, float* dz, int64_t lddz, float grad_scale, void* stream);
 /* last Linear(d, 1) of the discriminator (:43); when delta != NULL the same pass writes the seed
  * delta[r,j] = rowscale[r] * w[j] * slope[r,j] of the backward / input-gradient chain */
 int dpc_disc_out_fwd(const float* h, int64_t ldh, const float* w, const float* b, int64_t rows, int d,
