@@ -7,7 +7,7 @@
 // and, in the backward pass, the cond columns of dW are sums of the rows of dY that have that column
 // hot.  The kernels here keep those two pieces off the matrix cores: the forward share is a row gather
 // fused into the GEMM epilogue (dpc_gemm_f32_gather), fed by the transposed column slices kept by
-// dpc_transpose_slices; the backward share is dpc_hot_rows_scatter.  All HBM/L2-bound index work.
+// dpc_transpose_slices; the backward share is dpc_hot_sort + dpc_hot_rows_sum.  All HBM/L2-bound index work.
 #include "dpc_common.h"
 
 // ---------------------------------------------------------------------------------------------
