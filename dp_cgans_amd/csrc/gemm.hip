@@ -262,11 +262,12 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     }
   }
 
-  if (nmain > 0) {
+  if (nfull > 0) {
+    const int last = nfull - 1;
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      sa[j].load_fast(g.A, lda, m0, k_begin + j * BK, g.M, g.kscale);
-      sb[j].load_fast(g.B, ldb, n0, k_begin + j * BK, g.N);
+      sa[j].load_fast(g.A, lda, m0, k_begin + min(j, last) * BK, g.M, g.kscale);
+      sb[j].load_fast(g.B, ldb, n0, k_begin + min(j, last) * BK, g.N);
     }
     sa[0].store(As0);
     sb[0].store(Bs0);
@@ -275,7 +276,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int cur = u & 1;              // PF is even, so t & 1 == u & 1
-        const int tl = min(t0 + u + PF, nmain - 1);
+        const int tl = min(t0 + u + PF, last);
         sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
         sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
         compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
@@ -284,9 +285,25 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
         __syncthreads();
       }
     }
+    // The nfull - nmain (< PF) full tiles left over are in the ring already - the last pass above (or
+    // the prologue, when there was none) loaded them, and tile nmain sits in LDS buffer 0: they are
+    // consumed from there, still pipelined (they used to take the serial path below, ~3 us a tile).
+    const int rem = nfull - nmain;
+#pragma unroll
+    for (int u = 0; u + 1 < PF; ++u) {
+      if (u < rem) {
+        const int cur = u & 1;
+        compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
+        if (u + 1 < rem) {
+          sa[u + 1].store(As + (cur ^ 1) * SA::SIZE);
+          sb[u + 1].store(Bs + (cur ^ 1) * SB::SIZE);
+        }
+        __syncthreads();
+      }
+    }
   }
-  // Remainder (< PF full tiles, a partial last tile, or operands the fast path cannot take).
-  for (int t = nmain; t < ntile; ++t) {
+  // Remainder (a partial last tile, or operands the fast path cannot take): one tile at a time.
+  for (int t = nfull; t < ntile; ++t) {
     sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
     sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
     sa[0].store(As0);
@@ -485,6 +502,14 @@ extern "C" int dpc_gemm_config(int force_tile) {
   return DPC_OK;
 }
 
+static int g_prefetch = 0;
+// Tuning hook: depth of the register prefetch ring of the 64x64 tile: 0 = automatic, 2 or 4.  Host-side state.
+extern "C" int dpc_gemm_prefetch(int depth) {
+  if (depth != 0 && depth != 2 && depth != 4) return DPC_EINVAL;
+  g_prefetch = depth;
+  return DPC_OK;
+}
+
 template <int BM, int BN, int PF>
 static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n * g.splitk), block(256);
@@ -633,6 +658,7 @@ static int gemm_impl(int M, int N, int K, float alpha, const float* A, int64_t a
   else if (bm == 128 && bn == 128) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
   else if (bm == 128) launch_tile<128, 64, 2>(g, a_kc, b_kc, st);
   else if (bn == 128) launch_tile<64, 128, 2>(g, a_kc, b_kc, st);
+  else if (g_prefetch == 4) launch_tile<64, 64, 4>(g, a_kc, b_kc, st);
   else launch_tile<64, 64, 2>(g, a_kc, b_kc, st);
   if (deferred_epi)
     hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(dpc_grid((int64_t)M * N, 256)), dim3(256), 0, st, full);

@@ -75,6 +75,8 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
 /* tuning / test hook: force the GEMM block tile (0 automatic, 64 = 64x64, 128 = 128x128,
  * 12864 = 128x64, 64128 = 64x128).  Host-side state. */
 int dpc_gemm_config(int force_tile);
+/* tuning hook: depth of the 64x64 tile's register prefetch ring (0 automatic, 2, 4).  Host-side state. */
+int dpc_gemm_prefetch(int depth);
 /* reproducible mode: no automatic split-K (its fp32 atomics make the last bits order-dependent);
  * every other kernel of the library is bit-reproducible already.  Host-side state. */
 int dpc_set_deterministic(int on);

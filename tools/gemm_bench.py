@@ -34,7 +34,8 @@ def main():
     tot_ms, tot_fl = 0.0, 0.0
     from dp_cgans_amd._lib import lib
     TILES = [0]
-    lib().cdll.dpc_gemm_streamk_config(int(os.environ.get('DPC_STREAMK', '0')))     # -1: split-K, 0: stream-K (automatic)
+    lib().cdll.dpc_gemm_streamk_config(int(os.environ.get('DPC_STREAMK', '-1')))     # -1: split-K (the default), 0: stream-K (automatic)
+    lib().cdll.dpc_gemm_prefetch(int(os.environ.get('DPC_GEMM_PF', '0')))
     if len(sys.argv) > 1 and sys.argv[1] == 'tiles':
         TILES = [0, 64, 12864, 64128, 128]
     for tag, M, N, K, ta, tb, epi in [sh for sh in SHAPES for _ in TILES]:
