@@ -484,16 +484,20 @@ class StepEngine(object):
         ops.gemm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
                         bias=bias)
 
-    def _gen_dweight(self, c, l, dy, part):
-        """dW_l (+)= dy^T Hg[:, start[l]:] into the zeroed gradient buffer, and the bias gradient."""
+    def _gen_dweight(self, c, l, dy, part, what=3):
+        """dW_l (+)= dy^T Hg[:, start[l]:] into the zeroed gradient buffer (``what`` & 1: the product over the
+        dense input columns; & 2: the cond columns' row sums and the bias gradient)."""
         gw = self.gen.G('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
         gb = self.gen.G('seq.%d.fc.bias' % l if l < self.L else 'seq.%d.bias' % self.L)
         if self.sparse_cond and not ops.DETERMINISTIC:
-            ops.gemm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
-            ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
-        else:
+            if what & 1:
+                ops.gemm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
+            if what & 2:
+                ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
+        elif what & 1:
             ops.gemm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
-        self._colsum(dy, gb.view(1, -1), part=part)
+        if what & 2:
+            self._colsum(dy, gb.view(1, -1), part=part)
 
     def _gen_forward(self, c, running=True):
         """Generator forward into context ``c``.  ``running`` False leaves BatchNorm's running
@@ -926,8 +930,15 @@ class StepEngine(object):
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
                 ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
-            with self._fork((L - l) % 2) as part:               # after the chain's product, as above
-                self._gen_dweight(c, l, self.dZ[l], part)
+            if l == 0:
+                # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
+                # bias gradient while the product runs beside it
+                with self._fork((L - l) % 2) as part:
+                    self._gen_dweight(c, l, self.dZ[l], part, what=1)
+                self._gen_dweight(c, l, self.dZ[l], self.part, what=2)
+            else:
+                with self._fork((L - l) % 2) as part:           # after the chain's product, as above
+                    self._gen_dweight(c, l, self.dZ[l], part)
         self._join()
         if self.sparse_cond and not ops.DETERMINISTIC:
             # the scattered cond-column gradients into their places in the flat gradient buffer
