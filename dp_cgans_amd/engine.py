@@ -585,6 +585,7 @@ class StepEngine(object):
             self._so = so_b
             self._gen_linear(cb, self.L, cb.fake, g.P('seq.%d.bias' % self.L))
             self._activate({}, cb)
+            self._cond_loss_front(cb)
         self._so = so_a
         self._gen_linear(ca, self.L, ca.fake, g.P('seq.%d.bias' % self.L))
         self._activate({}, ca, raw=True)
@@ -889,6 +890,15 @@ class StepEngine(object):
                 ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._gen_forward(c, running=running)
         self._activate(inj, c)
+        self._cond_loss_front(c)
+
+    def _cond_loss_front(self, c):
+        """The conditional loss and its gradient (dp_cgan.py:711) need only the raw generator output and the
+        cond vector, so they belong to the front half of the generator update (which runs beside the
+        discriminator update): the gradient is WRITTEN to dfake here and the activation's backward adds to it."""
+        if self.has_cond:
+            self._ce_parts = ops.cond_loss(c.fake, c.cond, c.mask, self.col2d, self.col2c, self.nd, None,
+                                           self.dfake, self.part_loss, accumulate=False, batch_total=self.gB)
 
     def _g_back(self, inj, update, sub):
         self._so = 0 if sub is None else 64 * sub
@@ -899,10 +909,7 @@ class StepEngine(object):
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
         ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
-        ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans)
-        if self.has_cond:
-            self._ce_parts = ops.cond_loss(c.fake, c.cond, c.mask, self.col2d, self.col2c, self.nd, None,
-                                           self.dfake, self.part_loss, accumulate=True, batch_total=self.gB)
+        ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans, accumulate=self.has_cond)
         # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
