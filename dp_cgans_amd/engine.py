@@ -279,6 +279,7 @@ class StepEngine(object):
         self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
         self._g1_issued = False  # W1 W1^T of this discriminator update is already on its way (_draw_inputs)
+        self._pair_sort = False  # _gen_forward_pair issues the hot-id sort at the end of its second lane
         self._pair_R = {}        # row chunks of the paired forwards' column reductions, per layer
         self._early_open = False # the early stream holds work of _gen_forward_pair the main stream has not joined
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
@@ -547,13 +548,15 @@ class StepEngine(object):
                     s_.ctx.__exit__(*a)
                 return False
         if lanes:
-            self.early.wait_stream(main)            # cb's inputs were drawn on the main stream
+            self.early.wait_stream(main)            # whatever of cb's inputs was drawn on the main stream
         for l in range(self.L):
             F = self.gdim[l]
             b = g.P('seq.%d.fc.bias' % l)
             Rc = self._pair_R.get(l)
             if Rc is None or not lanes:
                 # first call (R, the number of row chunks of the reduction, is not known yet): one after the other
+                if lanes:
+                    main.wait_stream(self.early)
                 R = 0
                 for i, c in enumerate((ca, cb)):      # same shape, hence the same R: the two sets lie back to back
                     self._gen_linear(c, l, c.Z[l], b)
@@ -586,6 +589,8 @@ class StepEngine(object):
             self._gen_linear(cb, self.L, cb.fake, g.P('seq.%d.bias' % self.L))
             self._activate({}, cb)
             self._cond_loss_front(cb)
+            if self._pair_sort:          # the backward's hot-id sort at the lane's end, where nothing waits for it
+                ops.hot_sort(cb.sel, self.C, cb.order, cb.sid, cb.n_items)
         self._so = so_a
         self._gen_linear(ca, self.L, ca.fake, g.P('seq.%d.bias' % self.L))
         self._activate({}, ca, raw=True)
@@ -976,11 +981,24 @@ class StepEngine(object):
             self._so = 64 * last
             self._draw_inputs({}, need_real=True, c=self.cd)
             self._so = 64 * d_steps
-            self._gen_gx.zero_()
-            self._draw_inputs({}, need_real=False, c=self.cg)
-            if self.sparse_cond:
-                with self._fork(1):      # joined by the first collective; the generator backward reads it
-                    ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
+            if self.concurrent and self.early is not None:
+                # the generator update's inputs on its own lane (the early stream) as well
+                self.early.wait_stream(torch.cuda.current_stream(self.dev))
+                self._inline = True
+                try:
+                    with torch.cuda.stream(self.early):
+                        self._gen_gx.zero_()
+                        self._draw_inputs({}, need_real=False, c=self.cg)
+                finally:
+                    self._inline = False
+                self._pair_sort = self.sparse_cond
+            else:
+                self._gen_gx.zero_()
+                self._draw_inputs({}, need_real=False, c=self.cg)
+                self._pair_sort = False
+                if self.sparse_cond:
+                    with self._fork(1):      # joined by the first collective; the generator backward reads it
+                        ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
             self._gen_forward_pair(self.cd, self.cg, 64 * last, 64 * d_steps)
             self._d_back({}, True, last)
             self._join_early()
