@@ -22,6 +22,7 @@ Memory layout (all fp32, row-major, resident in HBM for the whole fit):
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -1093,7 +1094,10 @@ class GraphStep(object):
                 state['g'] = torch.cuda.CUDAGraph()
                 state['g'].capture_begin()
 
-            eng._ar_hook = cut
+            # DPCGAN_GRAPH_COLLECTIVES=1 (experimental, validated on one rank only): the RCCL all-reduces are
+            # captured into the graph instead of cutting it - one graph per step again
+            in_graph = os.environ.get('DPCGAN_GRAPH_COLLECTIVES') == '1' and getattr(eng.dist, 'backend', None) == 'nccl'
+            eng._ar_hook = None if in_graph else cut
             try:
                 self._body()
             finally:

@@ -104,7 +104,10 @@ def graph(dist, dev, mode):
     for _ in range(4):
         gs.run()
     torch.cuda.synchronize()
-    assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
+    if os.environ.get('DPCGAN_GRAPH_COLLECTIVES') == '1' and dist.backend == 'nccl':
+        assert len(gs.items) == 1, 'collectives captured: one graph per step'
+    else:
+        assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
     assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)
     assert torch.equal(a.disc.p, c.disc.p) and torch.equal(a.gen.p, c.gen.p), 'paired forwards changed the step'
     sa, sc = a.generator_state_dict(), c.generator_state_dict()
