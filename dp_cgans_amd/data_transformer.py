@@ -153,7 +153,6 @@ class DataTransformer(object):
         N = len(raw_data)
         out = torch.empty(N, self.output_dimensions, dtype=dtype, device=dev)
         o64, o32 = (out, None) if dtype == torch.float64 else (None, out)
-        rng = ops.new_rng(self._seed ^ 0xe2c0de, dev)
         col = 0
         for j, info in enumerate(self._column_transform_info_list):
             if info.column_type == 'continuous':
@@ -162,13 +161,17 @@ class DataTransformer(object):
                 vidx = torch.from_numpy(gt.valid_idx).to(dev)
                 x_all = np.ascontiguousarray(raw_data[info.column_name].to_numpy(dtype=np.float64))
                 u_all = None if uniforms is None else np.ascontiguousarray(uniforms[info.column_name], dtype=np.float64)
+                # one Philox stream per column (the key), one step per row chunk: the 16-bit call-site field
+                # carries neither, so no table size makes two chunks or columns share their draws
+                rng = ops.new_rng((self._seed ^ 0xe2c0de) + 0x9E3779B97F4A7C15 * (j + 1), dev)
                 for r0 in range(0, N, chunk):
                     r1 = min(N, r0 + chunk)
                     x = torch.from_numpy(x_all[r0:r1]).to(dev)
                     u = None if u_all is None else torch.from_numpy(u_all[r0:r1]).to(dev)
                     ops.encode_continuous(x, tab, vidx, out64=None if o64 is None else o64[r0:r1],
                                           out32=None if o32 is None else o32[r0:r1], col_off=col, u_inj=u, rng=rng,
-                                          site=ops.SITE_ENCODE + 2 * j + (r0 // chunk) * 4096)
+                                          site=ops.SITE_ENCODE)
+                    ops.state_advance(rng)
             else:
                 codes_all = info.transform.codes(raw_data[info.column_name])
                 for r0 in range(0, N, chunk):

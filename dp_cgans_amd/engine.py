@@ -150,10 +150,17 @@ class StepEngine(object):
 
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
-                 private=False, seed=0, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
+                 private=False, seed=None, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
                  weight_clip=None, gp_gram=None, sparse_cond=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
+        if seed is None:
+            # OS entropy keys every stream (parameter init, batch draws, DP noise), rank 0's on every rank:
+            # replicas must start from the same parameters and add the same noise.  A fixed seed is a test
+            # hook - it makes the private mode's Gaussian noise a publicly computable sequence.
+            seed = int.from_bytes(os.urandom(8), 'little') >> 1
+            if self.dist.active:
+                seed = self.dist.broadcast_int(seed, self.dev)
         self.span_info_np = np.asarray(span_info, dtype=np.int32).reshape(-1, 3)
         spans, cols, col2d, col2c = span_tables(span_info)
         self.Dd = int(spans[:, 1].sum())
@@ -679,17 +686,26 @@ class StepEngine(object):
         ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), self.y,
                          rowscale=self.rowscale_d, slope=self.S[M - 1], delta=self.Dl[M - 1])
 
-    def score_real_rows(self, inj=None):
-        """Discriminator output on a freshly sampled batch of real rows with their cond vectors
-        (what the reference's xai_discriminator evaluates, dp_cgan.py:896-928; Dropout on)."""
+    def score_real_rows(self, inj=None, rows=None):
+        """Discriminator output [rows / pac, 1] on freshly sampled real rows with their cond vectors
+        (what the reference's xai_discriminator evaluates for len(data_samples) rows, dp_cgan.py:896-928;
+        Dropout on).  Rows are drawn a batch at a time; ``rows`` defaults to one batch."""
         inj = inj or {}
-        self._so = 0
-        self._last = self.cd
-        self._draw_inputs(inj, need_real=True, c=self.cd)
-        self._join()
-        self._disc_forward(self.n, inj, row0=self.n, y=self.y_x)
-        ops.state_advance(self.rng)
-        return self.y_x.detach().cpu().view(-1, 1)
+        rows = self.B if rows is None else int(rows)
+        if rows % self.pac != 0:
+            raise AssertionError('rows %% pac != 0')            # dp_cgan.py:67
+        out = []
+        need = rows // self.pac
+        while need > 0:
+            self._so = 0
+            self._last = self.cd
+            self._draw_inputs(inj, need_real=True, c=self.cd)
+            self._join()
+            self._disc_forward(self.n, inj, row0=self.n, y=self.y_x)
+            ops.state_advance(self.rng)
+            out.append(self.y_x[:min(need, self.n)].detach().cpu())
+            need -= self.n
+        return torch.cat(out).view(-1, 1)
 
     def _disc_chain_down(self, rows, rowscale):
         """D_M = rowscale * w_last * S_M;  D_{i-1} = (D_i W_i) * S_{i-1}."""

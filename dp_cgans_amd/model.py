@@ -95,7 +95,8 @@ class _TableLite(object):
 class DP_CGAN(object):
     """Drop-in for ``dp_cgans.DP_CGAN``: same constructor arguments and defaults
     (dp_cgan_modular.py:73-80), ``fit(DataFrame)``, ``sample(num_rows)``, ``save``/``load``.
-    Extra keyword arguments of this build: ``dp_mode``, ``dp_sigma``, ``dp_clip``, ``seed``."""
+    Extra keyword arguments of this build: ``dp_mode``, ``dp_sigma``, ``dp_clip``, ``seed`` (None = OS
+    entropy; a fixed seed is a test hook that voids the privacy guarantee of ``private=True``)."""
 
     _MODEL_CLASS = DPCGANSynthesizer
 
@@ -107,7 +108,7 @@ class DP_CGAN(object):
                  log_frequency=True, verbose=False, epochs=300, pac=10, cuda=True,
                  rounding='auto', min_value='auto', max_value='auto', private=False,
                  wandb=False, ontology=None, saved_transformer=None, dp_mode='reference', dp_sigma=1.0,
-                 dp_clip=1.0, seed=0):
+                 dp_clip=1.0, seed=None):
         for name, arg in (('field_types', field_types), ('field_transformers', field_transformers),
                           ('anonymize_fields', anonymize_fields), ('primary_key', primary_key),
                           ('constraints', constraints), ('table_metadata', table_metadata)):

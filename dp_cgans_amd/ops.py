@@ -23,13 +23,27 @@ SITE_NOISE_D, SITE_HOOK, SITE_ENCODE = 7, 8, 9
 GEMM_PROFILE = None
 
 
+_dev_index = None        # GPU of the tensors of the call being assembled (see _stream)
+
+
 def _p(t):
+    global _dev_index
     if t is None:
         return None
+    if t.is_cuda:
+        _dev_index = t.device.index
     return ctypes.c_void_p(t.data_ptr())
 
 
 def _stream():
+    """The launch stream: the current stream of the GPU that holds the call's tensors.  Every wrapper
+    below converts its tensors (``_p``) before it asks for the stream, so a call whose tensors live on
+    another GPU than the current one is refused here instead of being launched on the wrong device's
+    stream with pointers into another device's memory."""
+    idx = _dev_index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError('dp_cgans_amd.ops: tensors on cuda:%d but the current device is cuda:%d; run under '
+                           '`with torch.cuda.device(%d):`' % (idx, torch.cuda.current_device(), idx))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

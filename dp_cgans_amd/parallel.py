@@ -11,10 +11,13 @@ import torch.distributed as dist
 
 
 class Dist(object):
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, device=None):
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        # the GPU this rank computes on (RCCL binds its communicator to the current device)
+        self.device_index = self.local_rank if device is None or torch.device(device).index is None \
+            else torch.device(device).index
         # DPCGAN_FORCE_DIST=1 runs the collectives even with a single rank: that is how the RCCL path
         # (process group, all-reduce on the device, graph segments cut at the collectives) is
         # exercised on a one-GPU box
@@ -25,7 +28,7 @@ class Dist(object):
             if backend is None:
                 backend = os.environ.get('DPCGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.device_index)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
         self.backend = dist.get_backend() if self.active else None
 
@@ -44,7 +47,7 @@ class Dist(object):
     def barrier(self):
         if self.active:
             if self.backend == 'nccl':
-                dist.barrier(device_ids=[self.local_rank])
+                dist.barrier(device_ids=[self.device_index])
             else:
                 dist.barrier()
 
@@ -53,6 +56,15 @@ class Dist(object):
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def broadcast_int(self, value, device):
+        """Rank 0's 63-bit integer on every rank (a sum in which only rank 0 contributes)."""
+        if not self.active:
+            return int(value)
+        t = torch.tensor([int(value) if self.rank == 0 else 0], dtype=torch.int64,
+                         device='cpu' if self.backend == 'gloo' else device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
 
     def shutdown(self):
         if self.active and dist.is_initialized():

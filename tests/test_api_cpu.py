@@ -36,6 +36,37 @@ def test_constructor_surface_matches_reference():
     assert m._model_kwargs['batch_size'] == 100 and m._model_kwargs['pac'] == 10
 
 
+def test_device_and_seed_contract_of_the_constructor():
+    """cuda=False (the reference's own test passes it, tests/test_dp_cgans.py:27) warns and keeps the GPU;
+    a CPU device string raises; seed defaults to None (OS entropy); a fixed seed with private=True warns
+    that the noise becomes reproducible; a batch that does not split into pac groups per rank raises."""
+    import warnings
+    from dp_cgans_amd import DP_CGAN, DPCGANSynthesizer
+    assert inspect.signature(DPCGANSynthesizer.__init__).parameters['seed'].default is None
+    assert inspect.signature(DP_CGAN.__init__).parameters['seed'].default is None
+    DPCGANSynthesizer._warned_no_cpu = False
+    with pytest.warns(UserWarning, match='no CPU path'):
+        s = DPCGANSynthesizer(cuda=False)
+    assert s._device.type == 'cuda'
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        DPCGANSynthesizer(cuda=False)                                  # one warning per process
+        DPCGANSynthesizer(private=True)                                # no seed: nothing to warn about
+    for dev in ('cpu', 'cpu:0'):
+        with pytest.raises(ValueError, match='not a GPU'):
+            DPCGANSynthesizer(cuda=dev)
+    assert DPCGANSynthesizer(cuda='cuda:3')._device.index == 3
+    with pytest.warns(UserWarning, match='voids the privacy guarantee'):
+        DPCGANSynthesizer(private=True, seed=1)
+    a, b = DPCGANSynthesizer()._base_seed(), DPCGANSynthesizer()._base_seed()
+    assert a != b and 0 <= a < 2 ** 63
+    assert DPCGANSynthesizer(seed=5)._base_seed() == 5
+    with pytest.raises(ValueError, match='multiple of world size x pac'):
+        DPCGANSynthesizer(batch_size=500, pac=8)._build_engine(np.array([[2, 1, 1]], dtype=np.int32))
+    from dp_cgans_amd.synthesizer import _derive_seed
+    assert _derive_seed(5, b'transformer') != 5 and _derive_seed(5, b'transformer') == _derive_seed(5, b'transformer')
+
+
 def test_table_preprocessing_matches_what_the_reference_hands_to_the_synthesizer():
     """Through the reference wrapper the Adult frame becomes 24 float columns, 19 of them binary
     one-hot columns treated as discrete; fixture captured from the reference."""

@@ -125,8 +125,43 @@ def test_reference_smoke_test_fit_and_sample_adult(in_tmp):
         assert torch.equal(v.cpu(), sd[k].cpu()), k
     out2 = m2.sample(50)
     assert len(out2) == 50 and list(out2.columns) == list(df.columns)
+    # xai_discriminator scores len(data_samples) rows (dp_cgan.py:899-915): [rows / pac, 1], whatever the batch size
     score = model.xai_discriminator(df.iloc[:10].T)
-    assert score.shape == (synth._engine.n, 1) and torch.isfinite(score).all()
+    assert score.shape == (1, 1) and torch.isfinite(score).all()
+    score = model.xai_discriminator(df.iloc[:150].T)         # more rows than one batch of 100
+    assert score.shape == (15, 1) and torch.isfinite(score).all()
+    with pytest.raises(AssertionError):
+        model.xai_discriminator(df.iloc[:7].T)               # Discriminator.forward's pac assert (dp_cgan.py:67)
+    # ---- device contract: cuda=False warns once and runs on the GPU; a CPU device string raises
+    from dp_cgans_amd import DPCGANSynthesizer
+    DPCGANSynthesizer._warned_no_cpu = False
+    with pytest.warns(UserWarning, match='no CPU path'):
+        s2 = DPCGANSynthesizer(cuda=False)
+    assert s2._device.type == 'cuda'
+    with pytest.raises(ValueError, match='not a GPU'):
+        synth.set_device('cpu')
+    synth.set_device('cuda:0')                              # same device: nothing to rebuild
+    assert synth._engine is eng
+
+
+def test_ops_refuse_a_call_whose_tensors_are_not_on_the_current_device():
+    """Launches go to the current stream of the tensors' GPU; with another GPU current the wrappers raise
+    instead of launching on the wrong device's stream (needs two visible GPUs)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two visible GPUs')
+    from dp_cgans_amd import DPCGANSynthesizer, ops
+    x = torch.zeros(8, 8, device='cuda:1')
+    with torch.cuda.device(0):
+        with pytest.raises(RuntimeError, match='current device'):
+            ops.fill(x, ops.FILL_UNIFORM, ops.new_rng(1, 'cuda:1'), 1)
+    rng = np.random.default_rng(0)
+    df = pd.DataFrame({'a': rng.normal(size=300), 'c': rng.integers(3, size=300).astype(str)})
+    s = DPCGANSynthesizer(epochs=2, batch_size=60, pac=10, generator_dim=(32,), discriminator_dim=(32,), embedding_dim=16,
+                          cuda='cuda:1', seed=3)
+    with torch.cuda.device(0):                               # the caller's current device is NOT the model's
+        s.fit(df, discrete_columns=['c'])
+        out = s.sample(40)
+    assert out.shape == (40, 2) and s._engine.gen.p.device.index == 1
 
 
 def _torch_generator(in_dim, gdims, data_dim):
