@@ -4,6 +4,7 @@
 // row reductions; reductions accumulate in fp64 and are bit-reproducible (fixed partial layout,
 // fixed summation order, no atomics).
 #include "dpc_common.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 // Column reductions over a [rows, F] matrix: grid (ceil(F/64), R), block 256 = 64 columns x 4 row
@@ -164,6 +165,62 @@ extern "C" int dpc_colreduce_finish(const double* part, int R, int nout, int F, 
   DPC_CHECK_ARG(kind != 0 || (nout == 2 && count > 0.0), "colreduce_finish: statistics need two sums and a count");
   hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 64)), dim3(256), 0, (hipStream_t)stream, part,
                      R, nout, F, kind, count, eps, momentum, out0, out1, run_mean, run_var, accumulate);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dpc_colsum_noalloc: the weighted column sums of dpc_colreduce_partial(mode 1) + dpc_colreduce_finish
+// (kind 1) in one call whose row-chunk partials live in a file-scope device array instead of a
+// caller-provided workspace - for callers that cannot allocate (code under graph capture, serving
+// loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+// `scratch` is a HOST-SIDE STAND-IN in host code, not a device address: each GPU holds its own copy at
+// its own address, looked up once per device with hipGetSymbolAddress and kept in g_scratch_ptr;
+// kernels, memsets and copies only ever see that pointer.
+// ---------------------------------------------------------------------------------------------
+#define DPC_NOALLOC_MAX_F 8192
+#define DPC_NOALLOC_MAX_R 64
+#define DPC_NOALLOC_MAX_DEV 64
+static __device__ __align__(256) double scratch[(size_t)DPC_NOALLOC_MAX_R * DPC_NOALLOC_MAX_F];     // 4 MiB per GPU
+static double* g_scratch_ptr[DPC_NOALLOC_MAX_DEV];
+static std::mutex g_scratch_mu;
+
+static int noalloc_scratch(double** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
+  DPC_CHECK_ARG(dev >= 0 && dev < DPC_NOALLOC_MAX_DEV, "colsum_noalloc: device index beyond 63");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));      // this device's copy of the array
+    if (e != hipSuccess || !p) { dpc_set_error(e != hipSuccess ? hipGetErrorString(e) : "hipGetSymbolAddress returned null"); return DPC_EHIP; }
+    g_scratch_ptr[dev] = static_cast<double*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return DPC_OK;
+}
+
+// out[f] (+)= sum_r w[r] * x[r, f] (w nullable = 1): the same two kernels, the same row-chunk count R
+// and the same summation order as dpc_colreduce_partial(mode 1, max_R 64) followed by
+// dpc_colreduce_finish(kind 1) - bit-identical results.  Allocates nothing; F <= 8192.  Every call on
+// a GPU uses that GPU's one scratch array (all R x F partials it reads are rewritten first, nothing
+// needs clearing): calls that overlap on one GPU - two streams, two threads - race.
+extern "C" int dpc_colsum_noalloc(const float* x, int64_t ldx, int64_t rows, int F, const float* w, float* out,
+                                  int accumulate, void* stream) {
+  DPC_CHECK_ARG(x && out, "colsum_noalloc: null pointer");
+  DPC_CHECK_ARG(rows > 0 && F > 0 && ldx >= F, "colsum_noalloc: bad shape");
+  DPC_CHECK_ARG(F <= DPC_NOALLOC_MAX_F, "colsum_noalloc: more than 8192 columns (the static scratch holds 64 x 8192 partial sums)");
+  double* part = nullptr;
+  int rc = noalloc_scratch(&part);
+  if (rc != DPC_OK) return rc;
+  ColArgs a;
+  a.x = x; a.ldx = ldx; a.rows = rows; a.F = F; a.w = w; a.y = nullptr; a.ldy = 0; a.z = nullptr; a.ldz = 0; a.mean = nullptr;
+  a.invstd = nullptr; a.part = part; a.R = pick_R(rows, F, DPC_NOALLOC_MAX_R);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3((unsigned)dpc_cdiv(F, 64), a.R), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)dpc_cdiv(F, 64)), dim3(256), 0, st, part, a.R, 1, F, 1, 1.0,
+                     0.f, 0.f, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

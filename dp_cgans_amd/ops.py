@@ -335,6 +335,18 @@ def colreduce_finish(part, R, nout, F, kind, out0, out1=None, count=1.0, eps=1e-
                _p(run_mean), _p(run_var), int(accumulate), _stream())
 
 
+def colsum_noalloc(x, out, w=None, accumulate=False):
+    """out[f] (+)= sum_r w[r] x[r, f] through the library's static scratch (no workspace, no allocation)."""
+    _chk(x, torch.float32, 'x')
+    _chk(out, torch.float32, 'out')
+    _chk(w, torch.float32, 'w')
+    rows, F = x.shape
+    if out.numel() != F or (w is not None and w.numel() != rows):
+        raise ValueError('colsum_noalloc: out needs F entries, w one per row')
+    lib().call('dpc_colsum_noalloc', _p(x), _ld(x), rows, F, _p(w), _p(out), int(accumulate), _stream())
+    return out
+
+
 def bn_relu_fwd(z, y, mean, invstd, gamma, beta):
     lib().call('dpc_bn_relu_fwd', _p(z), _ld(z), _p(y), _ld(y), z.shape[0], z.shape[1], _p(mean), _p(invstd), _p(gamma),
                _p(beta), _stream())

@@ -231,6 +231,14 @@ int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int64_t rows, i
 int dpc_colreduce_finish(const double* part, int R, int nout, int F, int kind, double count, float eps,
                          float momentum, float* out0, float* out1, float* run_mean, float* run_var,
                          int accumulate, void* stream);
+/* out[f] (+)= sum_r w[r] * x[r*ldx + f] (w nullable = all ones): dpc_colreduce_partial(mode 1, max_R 64) +
+ * dpc_colreduce_finish(kind 1) in one call that ALLOCATES NOTHING and takes no workspace: the row-chunk
+ * partial sums live in a 4 MiB file-scope device array of the library (one copy per GPU, held until the
+ * process ends).  No counterpart in the reference; it is for callers that cannot allocate (HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  Bit-identical to that pair of calls.
+ * F <= 8192 (DPC_EINVAL beyond).  Calls that overlap on one GPU share the array and race. */
+int dpc_colsum_noalloc(const float* x, int64_t ldx, int64_t rows, int F, const float* w, float* out,
+                       int accumulate, void* stream);
 int dpc_bn_relu_fwd(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F,
                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                     void* stream);
