@@ -5,11 +5,339 @@
 // the gradient) per element plus the cond/mask rows for the loss.
 #include "dpc_common.h"
 
+// ---------------------------------------------------------------------------------------------
+// Tiled form (rows short enough for R >= 1 of them to sit in LDS): a block owns R consecutive rows.
+//   phase 1  one thread per Philox block of 4 consecutive flat indices b*Dd + col: reads the 4 raw
+//            outputs, draws / reads their Exp(1) numbers and leaves t = (x - log E) / tau in LDS - every
+//            Philox block is computed exactly once, and consecutive threads touch consecutive addresses.
+//            The conditional loss (dpc_activate_cond_loss_fwd) is taken here too: it needs exactly the
+//            raw outputs this phase has in registers.
+//   phase 2  one thread per (row, span): softmax over the span's LDS values (max, exp, sum in column
+//            order, scale by 1/sum - the arithmetic and order of the wide-row kernel); tanh spans read
+//            their raw value again (L2-hot, one element per continuous column).
+//   phase 3  the tile goes out with coalesced stores.
+// The wide-row kernel (one thread per (row, span), straight from global memory) stays as the path for
+// rows longer than the LDS tile.
+// ---------------------------------------------------------------------------------------------
+struct ActFwdArgs {
+  const float* x; int64_t ldx; float* y; int64_t ldy; const int32_t* spans; int nspan; int64_t B; int Dd;
+  const float* en; int64_t ld_en; const uint64_t* rng; uint32_t site; float inv_tau;
+  int R;                      // rows per tile
+  // conditional loss (dfake != NULL || partials != NULL): see dpc_activate_cond_loss_fwd
+  const float* cond; int64_t ldc; const int32_t* mask; int64_t ldm; const int32_t* col2d; const int32_t* col2c;
+  float scale; float* dfake; int64_t lddf; double* partials;
+};
+
+template <bool LOSS>
+__global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];       // [R][Dd]
+  __shared__ double red[16];
+  const uint32_t Dd = (uint32_t)a.Dd;
+  double acc = 0.0;
+  const int64_t ntiles = (a.B + a.R - 1) / a.R;
+  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int64_t b0 = tix * a.R;
+    const uint32_t rows = (uint32_t)min((int64_t)a.R, a.B - b0);
+    const uint32_t nel = rows * Dd;
+    // ---- phase 1
+    const uint64_t f0 = (uint64_t)b0 * Dd, f1 = f0 + nel;
+    const uint64_t q0 = f0 >> 2, q1 = (f1 + 3) >> 2;
+    for (uint64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+      DpcPhilox4 ph;
+      if (!a.en) ph = dpc_philox(a.rng[0], a.rng[1], a.site, q);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const uint64_t f = (q << 2) + l;
+        if (f < f0 || f >= f1) continue;
+        const uint32_t e = (uint32_t)(f - f0);
+        const uint32_t r = e / Dd, col = e - r * Dd;
+        const int64_t b = b0 + r;
+        const float xv = a.x[b * a.ldx + col];
+        const float ev = a.en ? a.en[b * a.ld_en + col] : -logf(dpc_u32_to_unit(ph.v[l]));
+        tile[e] = (xv - logf(ev)) * a.inv_tau;
+        if (LOSS) {
+          const int d = a.col2d[col];
+          float gval = 0.f;
+          if (d >= 0) {
+            const float m = (float)a.mask[b * a.ldm + d];
+            if (m != 0.f) {
+              const float c = a.cond[b * a.ldc + a.col2c[col]];
+              const float ex = expf(-fabsf(xv));
+              acc += (double)(m * (fmaxf(xv, 0.f) - xv * c + log1pf(ex)));
+              const float sig = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
+              gval = a.scale * m * (sig - c);
+            }
+          }
+          if (a.dfake) a.dfake[b * a.lddf + col] = gval;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2
+    const uint32_t nitem = rows * (uint32_t)a.nspan;
+    for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
+      const uint32_t r = it / (uint32_t)a.nspan, s = it - r * (uint32_t)a.nspan;
+      const int off = a.spans[3 * s], dim = a.spans[3 * s + 1], kind = a.spans[3 * s + 2];
+      float* tr = tile + r * Dd + off;
+      if (kind == 0) {
+        const float* xr = a.x + (b0 + r) * a.ldx + off;
+        for (int j = 0; j < dim; ++j) tr[j] = tanhf(xr[j]);
+      } else {
+        float mx = -INFINITY;
+        for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
+        float sum = 0.f;
+        for (int j = 0; j < dim; ++j) {
+          const float ev = expf(tr[j] - mx);
+          tr[j] = ev;
+          sum += ev;
+        }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < dim; ++j) tr[j] *= inv;
+      }
+    }
+    __syncthreads();
+    // ---- phase 3
+    for (uint32_t e = threadIdx.x; e < nel; e += 256) {
+      const uint32_t r = e / Dd, col = e - r * Dd;
+      a.y[(b0 + r) * a.ldy + col] = tile[e];
+    }
+    __syncthreads();
+  }
+  if (LOSS && a.partials) {
+    const double tot = dpc_block_sum(acc, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+  }
+}
+
+// The same three phases with every table in LDS as well (narrow rows: Adult, T1M, T10M): a phase 0
+// brings the raw tile (and the tile's mask rows) in with independent coalesced loads - all of a thread's
+// loads in flight at once - so that phases 1 and 2 touch global memory only for stores (and for the few
+// cond-vector entries behind a set mask bit).  LDS: xs[R*Dd] raw | ts[R*Dd] | spans[3*nspan] |
+// LOSS: col2d[Dd] | col2c[Dd] | mask tile [R*nd].
+// What bounds this kernel is instruction issue (8 resident blocks per CU, ~1000 instructions per thread)
+// and the barrier wait for the slowest wave, so: rows are walked by loops instead of flat indices (a 32-bit
+// division by the runtime row length is ~30 instructions), a Philox block's four elements share one
+// division, the host picks R so that the tile's Philox blocks fill whole rounds of 256 threads, spans of up
+// to 4 columns - all of them through the reference's public wrapper - stay in registers, and the
+// conditional loss is taken per SPAN in phase 2: only the two chosen discrete columns of a row contribute
+// (mask bit set), so the transcendental path runs for ~1 lane in 64 instead of diverging every wave.
+template <bool LOSS>
+__global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, int nd) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ double red[16];
+  const uint32_t Dd = (uint32_t)a.Dd, R = (uint32_t)a.R, nspan = (uint32_t)a.nspan;
+  float* xs = tile;                       // raw tile; phase 2 turns it into the loss gradient (LOSS)
+  float* ts = tile + R * Dd;
+  int32_t* sp = reinterpret_cast<int32_t*>(ts + R * Dd);
+  int32_t* c2d = sp + 3 * nspan;
+  int32_t* c2c = c2d + Dd;
+  int32_t* mk = c2c + Dd;
+  for (uint32_t i = threadIdx.x; i < 3 * nspan; i += 256) sp[i] = a.spans[i];
+  if (LOSS) {
+    for (uint32_t i = threadIdx.x; i < Dd; i += 256) {
+      c2d[i] = a.col2d[i];
+      c2c[i] = a.col2c[i];
+    }
+  }
+  double acc = 0.0;
+  const float inv_dd = 1.0f / (float)Dd;
+  const int64_t ntiles = (a.B + R - 1) / R;
+  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int64_t b0 = tix * R;
+    const uint32_t rows = (uint32_t)min((int64_t)R, a.B - b0);
+    const uint32_t nel = rows * Dd;
+    // ---- phase 0: raw tile (and mask rows), every load independent
+    const float* __restrict__ xg = a.x + b0 * a.ldx;
+    for (uint32_t r = 0; r < rows; ++r)
+      for (uint32_t col = threadIdx.x; col < Dd; col += 256) xs[r * Dd + col] = xg[r * a.ldx + col];
+    if (LOSS) {
+      const int32_t* __restrict__ mg = a.mask + b0 * a.ldm;
+      for (uint32_t r = 0; r < rows; ++r)
+        for (uint32_t d = threadIdx.x; d < (uint32_t)nd; d += 256) mk[r * (uint32_t)nd + d] = mg[r * a.ldm + d];
+    }
+    __syncthreads();
+    // ---- phase 1
+    const uint64_t f0 = (uint64_t)b0 * Dd, f1 = f0 + nel;
+    const uint64_t q0 = f0 >> 2, q1 = (f1 + 3) >> 2;
+    for (uint64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+      DpcPhilox4 ph;
+      if (!a.en) ph = dpc_philox(a.rng[0], a.rng[1], a.site, q);
+      const uint64_t fq = q << 2;
+      const int lo = fq < f0 ? (int)(f0 - fq) : 0;                    // first of the four that lies inside the tile
+      uint32_t e = (uint32_t)(fq + lo - f0);
+      uint32_t r = (uint32_t)((float)e * inv_dd);                      // e / Dd, corrected: e < 2^16 here
+      if ((r + 1) * Dd <= e) ++r;
+      if (r * Dd > e) --r;
+      uint32_t col = e - r * Dd;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        if (l < lo || e >= nel) continue;
+        const float ev = a.en ? a.en[(b0 + r) * a.ld_en + col] : -logf(dpc_u32_to_unit(ph.v[l]));
+        ts[e] = (xs[e] - logf(ev)) * a.inv_tau;
+        ++e;
+        if (++col == Dd) { col = 0; ++r; }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: one thread per (row, span)
+    for (uint32_t r = 0; r < rows; ++r) {
+      for (uint32_t s = threadIdx.x; s < nspan; s += 256) {
+        const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
+        float* tr = ts + r * Dd + off;
+        float* xr = xs + r * Dd + off;
+        if (kind == 0) {
+          for (int j = 0; j < dim; ++j) {
+            tr[j] = tanhf(xr[j]);
+            if (LOSS) xr[j] = 0.f;
+          }
+          continue;
+        }
+        if (dim <= 4) {
+          float t[4];
+          float mx = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[j] = j < dim ? tr[j] : -INFINITY;
+            mx = fmaxf(mx, t[j]);
+          }
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < dim) {
+              t[j] = expf(t[j] - mx);
+              sum += t[j];
+            }
+          }
+          const float inv = 1.f / sum;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < dim) tr[j] = t[j] * inv;
+        } else {
+          float mx = -INFINITY;
+          for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
+          float sum = 0.f;
+          for (int j = 0; j < dim; ++j) {
+            const float ev = expf(tr[j] - mx);
+            tr[j] = ev;
+            sum += ev;
+          }
+          const float inv = 1.f / sum;
+          for (int j = 0; j < dim; ++j) tr[j] *= inv;
+        }
+        if (LOSS) {
+          const int d = c2d[off];                 // >= 0: a discrete column (its span is the whole column)
+          const float m = d >= 0 ? (float)mk[r * (uint32_t)nd + d] : 0.f;
+          if (m != 0.f) {
+            const float* cr = a.cond + (b0 + r) * a.ldc + c2c[off];
+            for (int j = 0; j < dim; ++j) {
+              const float xv = xr[j], c = cr[j];
+              const float ex = expf(-fabsf(xv));
+              acc += (double)(m * (fmaxf(xv, 0.f) - xv * c + log1pf(ex)));
+              const float sig = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
+              xr[j] = a.scale * m * (sig - c);
+            }
+          } else {
+            for (int j = 0; j < dim; ++j) xr[j] = 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3
+    float* __restrict__ yg = a.y + b0 * a.ldy;
+    for (uint32_t r = 0; r < rows; ++r)
+      for (uint32_t col = threadIdx.x; col < Dd; col += 256) yg[r * a.ldy + col] = ts[r * Dd + col];
+    if (LOSS && a.dfake) {
+      float* __restrict__ dg = a.dfake + b0 * a.lddf;
+      for (uint32_t r = 0; r < rows; ++r)
+        for (uint32_t col = threadIdx.x; col < Dd; col += 256) dg[r * a.lddf + col] = xs[r * Dd + col];
+    }
+    __syncthreads();
+  }
+  if (LOSS && a.partials) {
+    const double tot = dpc_block_sum(acc, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
+  }
+}
+
+// rows per LDS tile: as many as fit 32 KB, at most 8 (more blocks beat longer tiles: the kernel is
+// latency-bound at a few blocks per CU); 0 = a row does not fit the 128 KB a block may take
+static int act_tile_rows(int Dd, int64_t B, int arrays) {
+  const int64_t row_bytes = (int64_t)Dd * 4 * arrays;
+  int64_t R = (32 << 10) / row_bytes;
+  if (R > 8) R = 8;
+  if (R < 1) R = (row_bytes <= (128 << 10)) ? 1 : 0;
+  if (R > B) R = B;
+  return (int)R;
+}
+
+static int act_set_lds(const void* fn, size_t bytes) {
+  if (bytes <= (48u << 10)) return DPC_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
+  return DPC_OK;
+}
+
+struct ActBwdArgs {
+  const float* y; int64_t ldy; const float* dy; int64_t lddy; float* dx; int64_t lddx;
+  const int32_t* spans; int nspan; int64_t B; int Dd; float inv_tau; int accumulate; int R;
+};
+
+// Backward, same tiling: y and dy tiles in LDS (coalesced loads), one thread per (row, span) turns dy into
+// the span's input gradient in place, coalesced (accumulating) stores.
+template <bool SPL>      // SPL: the span table sits in LDS behind the tiles
+__global__ __launch_bounds__(256) void activate_bwd_tiled_kernel(ActBwdArgs a, int rshift) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];       // y [R][Dd], then dy [R][Dd]
+  const uint32_t Dd = (uint32_t)a.Dd, R = (uint32_t)a.R, nspan = (uint32_t)a.nspan;   // R = 1 << rshift
+  const int64_t ntiles = (a.B + R - 1) / R;
+  float* ty = tile;
+  float* tg = tile + (size_t)R * Dd;
+  int32_t* sp = reinterpret_cast<int32_t*>(tg + (size_t)R * Dd);
+  if (SPL)
+    for (uint32_t i = threadIdx.x; i < 3u * nspan; i += 256) sp[i] = a.spans[i];
+  const int32_t* spans = SPL ? sp : a.spans;
+  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int64_t b0 = tix * R;
+    const uint32_t rows = (uint32_t)min((int64_t)R, a.B - b0);
+    const float* __restrict__ yg = a.y + b0 * a.ldy;
+    const float* __restrict__ gg = a.dy + b0 * a.lddy;
+    for (uint32_t r = 0; r < rows; ++r)
+      for (uint32_t col = threadIdx.x; col < Dd; col += 256) {
+        ty[r * Dd + col] = yg[r * a.ldy + col];
+        tg[r * Dd + col] = gg[r * a.lddy + col];
+      }
+    __syncthreads();
+    const uint32_t r = threadIdx.x >> (8 - rshift), tpr = 256u >> rshift;     // 256 / R threads per row
+    if (r < rows) {
+      for (uint32_t s = threadIdx.x & (tpr - 1); s < nspan; s += tpr) {
+        const int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
+        const float* yr = ty + r * Dd + off;
+        float* gr = tg + r * Dd + off;
+        if (kind == 0) {
+          for (int j = 0; j < dim; ++j) gr[j] = gr[j] * (1.f - yr[j] * yr[j]);
+        } else {
+          float dot = 0.f;
+          for (int j = 0; j < dim; ++j) dot += yr[j] * gr[j];
+          for (int j = 0; j < dim; ++j) gr[j] = a.inv_tau * yr[j] * (gr[j] - dot);
+        }
+      }
+    }
+    __syncthreads();
+    float* dg = a.dx + b0 * a.lddx;
+    for (uint32_t r2 = 0; r2 < rows; ++r2)
+      for (uint32_t col = threadIdx.x; col < Dd; col += 256) {
+        float* dp = dg + r2 * a.lddx + col;
+        *dp = a.accumulate ? *dp + tg[r2 * Dd + col] : tg[r2 * Dd + col];
+      }
+    __syncthreads();
+  }
+}
+
 // span table rows: (offset, dim, kind) kind 0 = tanh, 1 = gumbel-softmax
 // IT: index type of the flattened (row, span) loop; uint32_t whenever it fits (a 64-bit division per
 // thread is ~100 instructions, which showed in a kernel that does ~15 elements per row and span)
 template <typename IT>
-__global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+__global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                            int64_t ldy, const int32_t* __restrict__ spans, int nspan,
                                                            int64_t B, int Dd, const float* __restrict__ en, int64_t ld_en,
                                                            const uint64_t* rng, uint32_t site, float inv_tau) {
@@ -71,6 +399,58 @@ __global__ __launch_bounds__(256) void activate_fwd_kernel(const float* __restri
   }
 }
 
+static int activate_fwd_impl(ActFwdArgs a, bool loss, int nd, int n_partials, int* n_used, float tau, hipStream_t st) {
+  a.inv_tau = 1.0f / tau;
+  // narrow rows: raw tile, result tile and every table in LDS (activate_fwd_small_kernel).  R: among 1..8
+  // rows (<= 24 KB of LDS) the count whose Philox blocks (R*Dd/4) fill rounds of 256 threads best
+  {
+    int64_t best = 0;
+    double best_u = 0.0;
+    for (int64_t R = 1; R <= 8 && R <= a.B; ++R) {
+      const size_t lds = ((size_t)2 * R * a.Dd + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
+      if (lds > (24u << 10)) break;
+      const double blocks = (double)R * a.Dd / 4.0;
+      const double u = blocks / (256.0 * (double)dpc_cdiv((int64_t)blocks + 1, 256));
+      if (u > best_u + 0.02) { best_u = u; best = R; }
+    }
+    if (best > 0) {
+      const int64_t R = best;
+      const size_t lds = ((size_t)2 * R * a.Dd + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
+      a.R = (int)R;
+      const int64_t ntiles = dpc_cdiv(a.B, R);
+      int64_t grid = ntiles < 8192 ? ntiles : 8192;
+      if (loss && grid > n_partials) grid = n_partials;
+      if (loss) hipLaunchKernelGGL(activate_fwd_small_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, a, nd);
+      else hipLaunchKernelGGL(activate_fwd_small_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, a, nd);
+      if (n_used) *n_used = (int)grid;
+      DPC_LAUNCH_CHECK();
+      return DPC_OK;
+    }
+  }
+  a.R = act_tile_rows(a.Dd, a.B, 1);
+  DPC_CHECK_ARG(a.R > 0 || !loss, "activate_cond_loss_fwd: rows beyond 32768 columns do not fit the LDS tile");
+  if (a.R > 0) {
+    const int64_t ntiles = dpc_cdiv(a.B, a.R);
+    int64_t grid = ntiles < 4096 ? ntiles : 4096;
+    if (loss && grid > n_partials) grid = n_partials;
+    const size_t lds = (size_t)a.R * a.Dd * sizeof(float);
+    const void* fn = loss ? (const void*)activate_fwd_tiled_kernel<true> : (const void*)activate_fwd_tiled_kernel<false>;
+    int rc = act_set_lds(fn, lds);
+    if (rc != DPC_OK) return rc;
+    if (loss) hipLaunchKernelGGL(activate_fwd_tiled_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(activate_fwd_tiled_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, a);
+    if (n_used) *n_used = (int)grid;
+  } else if (a.B * a.nspan < (1LL << 31)) {
+    hipLaunchKernelGGL(activate_fwd_wide_kernel<uint32_t>, dim3(dpc_grid(a.B * a.nspan, 256)), dim3(256), 0, st, a.x, a.ldx, a.y,
+                       a.ldy, a.spans, a.nspan, a.B, a.Dd, a.en, a.ld_en, a.rng, a.site, a.inv_tau);
+  } else {
+    hipLaunchKernelGGL(activate_fwd_wide_kernel<int64_t>, dim3(dpc_grid(a.B * a.nspan, 256)), dim3(256), 0, st, a.x, a.ldx, a.y,
+                       a.ldy, a.spans, a.nspan, a.B, a.Dd, a.en, a.ld_en, a.rng, a.site, a.inv_tau);
+  }
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
 extern "C" int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
                                       int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
                                       const uint64_t* rng, uint32_t site, float tau, void* stream) {
@@ -78,20 +458,39 @@ extern "C" int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int
   DPC_CHECK_ARG(exp_noise || rng, "apply_activate_fwd: no noise source");
   DPC_CHECK_ARG(B >= 0 && nspan >= 0 && ldx >= Dd && ldy >= Dd && tau > 0.f, "apply_activate_fwd: bad shape");
   if (B == 0 || nspan == 0) return DPC_OK;
-  if (B * nspan < (1LL << 31))
-    hipLaunchKernelGGL(activate_fwd_kernel<uint32_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
-  else
-    hipLaunchKernelGGL(activate_fwd_kernel<int64_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, y, ldy, spans, nspan, B, Dd, exp_noise, ld_noise, rng, site, 1.0f / tau);
-  DPC_LAUNCH_CHECK();
-  return DPC_OK;
+  ActFwdArgs a = {};
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.spans = spans; a.nspan = nspan; a.B = B; a.Dd = Dd; a.en = exp_noise;
+  a.ld_en = ld_noise; a.rng = rng; a.site = site;
+  return activate_fwd_impl(a, false, 0, 0, nullptr, tau, (hipStream_t)stream);
+}
+
+// _apply_activate and _cond_loss_pair (closed form, see dpc_cond_loss) of the generator update in ONE pass
+// over the raw generator output: y = activation(x), dfake = d cond-loss / d x (written, zero outside the
+// discrete columns), partials[0 : *n_used] = block sums of the un-scaled loss.
+extern "C" int dpc_activate_cond_loss_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
+                                          int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
+                                          const uint64_t* rng, uint32_t site, float tau, const float* cond,
+                                          int64_t ldc, const int32_t* mask, int64_t ldm, const int32_t* col2d,
+                                          const int32_t* col2c, int nd, int64_t B_total, float* dfake, int64_t lddf,
+                                          double* partials, int n_partials, int* n_used, void* stream) {
+  DPC_CHECK_ARG(x && y && spans && cond && mask && col2d && col2c && partials && n_used, "activate_cond_loss_fwd: null pointer");
+  DPC_CHECK_ARG(exp_noise || rng, "activate_cond_loss_fwd: no noise source");
+  DPC_CHECK_ARG(B > 0 && nspan > 0 && nd > 0 && ldx >= Dd && ldy >= Dd && tau > 0.f && n_partials >= 1,
+                "activate_cond_loss_fwd: bad shape");
+  DPC_CHECK_ARG(!dfake || lddf >= Dd, "activate_cond_loss_fwd: lddf < Dd");
+  if (B_total <= 0) B_total = B;
+  ActFwdArgs a = {};
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.spans = spans; a.nspan = nspan; a.B = B; a.Dd = Dd; a.en = exp_noise;
+  a.ld_en = ld_noise; a.rng = rng; a.site = site;
+  a.cond = cond; a.ldc = ldc; a.mask = mask; a.ldm = ldm; a.col2d = col2d; a.col2c = col2c;
+  a.scale = (float)(2.0 / ((double)B_total * (double)nd)); a.dfake = dfake; a.lddf = lddf; a.partials = partials;
+  return activate_fwd_impl(a, true, nd, n_partials, n_used, tau, (hipStream_t)stream);
 }
 
 // dx = dL/dx given y (saved activations) and dy.  tanh: dy (1 - y^2); softmax((x+g)/tau):
 // (1/tau) y (dy - sum_j y_j dy_j).  accumulate != 0 adds into dx.
 template <typename IT>
-__global__ __launch_bounds__(256) void activate_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+__global__ __launch_bounds__(256) void activate_bwd_wide_kernel(const float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ dy, int64_t lddy,
                                                            float* __restrict__ dx, int64_t lddx,
                                                            const int32_t* __restrict__ spans, int nspan, int64_t B,
@@ -142,17 +541,40 @@ __global__ __launch_bounds__(256) void activate_bwd_kernel(const float* __restri
 }
 
 extern "C" int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx,
-                                      int64_t lddx, const int32_t* spans, int nspan, int64_t B, float tau,
+                                      int64_t lddx, const int32_t* spans, int nspan, int64_t B, int Dd, float tau,
                                       int accumulate, void* stream) {
   DPC_CHECK_ARG(y && dy && dx && spans, "apply_activate_bwd: null pointer");
-  DPC_CHECK_ARG(B >= 0 && nspan >= 0 && tau > 0.f, "apply_activate_bwd: bad shape");
+  DPC_CHECK_ARG(B >= 0 && nspan >= 0 && tau > 0.f && Dd > 0 && ldy >= Dd && lddy >= Dd && lddx >= Dd, "apply_activate_bwd: bad shape");
   if (B == 0 || nspan == 0) return DPC_OK;
-  if (B * nspan < (1LL << 31))
-    hipLaunchKernelGGL(activate_bwd_kernel<uint32_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y,
+  hipStream_t st = (hipStream_t)stream;
+  int R = act_tile_rows(Dd, B, 2);
+  if (R > 0) {
+    // narrow rows: 4-row tiles and the span table in LDS (8 blocks per CU in flight)
+    const bool spl = (size_t)(2 * 4 * Dd + 3 * nspan) * 4 <= (20u << 10);
+    if (spl && R > 4) R = 4;
+    int rshift = 0;
+    while ((2 << rshift) <= R) ++rshift;
+    R = 1 << rshift;                       // a power of two: 256 / R threads per row
+    ActBwdArgs a;
+    a.y = y; a.ldy = ldy; a.dy = dy; a.lddy = lddy; a.dx = dx; a.lddx = lddx; a.spans = spans; a.nspan = nspan; a.B = B;
+    a.Dd = Dd; a.inv_tau = 1.0f / tau; a.accumulate = accumulate; a.R = R;
+    const int64_t ntiles = dpc_cdiv(B, R);
+    const size_t lds = ((size_t)2 * R * Dd + (spl ? 3 * (size_t)nspan : 0)) * sizeof(float);
+    const unsigned grid = (unsigned)(ntiles < 8192 ? ntiles : 8192);
+    if (spl) {
+      hipLaunchKernelGGL(activate_bwd_tiled_kernel<true>, dim3(grid), dim3(256), lds, st, a, rshift);
+    } else {
+      int rc = act_set_lds((const void*)activate_bwd_tiled_kernel<false>, lds);
+      if (rc != DPC_OK) return rc;
+      hipLaunchKernelGGL(activate_bwd_tiled_kernel<false>, dim3(grid), dim3(256), lds, st, a, rshift);
+    }
+  } else if (B * nspan < (1LL << 31)) {
+    hipLaunchKernelGGL(activate_bwd_wide_kernel<uint32_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, st, y,
                        ldy, dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
-  else
-    hipLaunchKernelGGL(activate_bwd_kernel<int64_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, (hipStream_t)stream, y,
+  } else {
+    hipLaunchKernelGGL(activate_bwd_wide_kernel<int64_t>, dim3(dpc_grid(B * nspan, 256)), dim3(256), 0, st, y,
                        ldy, dy, lddy, dx, lddx, spans, nspan, B, 1.0f / tau, accumulate);
+  }
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -595,8 +595,7 @@ class StepEngine(object):
         with lane_b():
             self._so = so_b
             self._gen_linear(cb, self.L, cb.fake, g.P('seq.%d.bias' % self.L))
-            self._activate({}, cb)
-            self._cond_loss_front(cb)
+            self._activate_loss({}, cb)
             if self._pair_sort:          # the backward's hot-id sort at the lane's end, where nothing waits for it
                 ops.hot_sort(cb.sel, self.C, cb.order, cb.sid, cb.n_items)
         self._so = so_a
@@ -911,16 +910,20 @@ class StepEngine(object):
             with self._fork(1):      # beside the forward; the backward's weight gradients read it
                 ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._gen_forward(c, running=running)
-        self._activate(inj, c)
-        self._cond_loss_front(c)
+        self._activate_loss(inj, c)
 
-    def _cond_loss_front(self, c):
-        """The conditional loss and its gradient (dp_cgan.py:711) need only the raw generator output and the
-        cond vector, so they belong to the front half of the generator update (which runs beside the
-        discriminator update): the gradient is WRITTEN to dfake here and the activation's backward adds to it."""
-        if self.has_cond:
-            self._ce_parts = ops.cond_loss(c.fake, c.cond, c.mask, self.col2d, self.col2c, self.nd, None,
-                                           self.dfake, self.part_loss, accumulate=False, batch_total=self.gB)
+    def _activate_loss(self, inj, c):
+        """Output activation of the generator update plus the conditional loss and its gradient
+        (dp_cgan.py:697,711) in one pass over the raw generator output: both need only that output and the cond
+        vector, so they belong to the front half of the generator update (which runs beside the discriminator
+        update).  The loss gradient is WRITTEN to dfake here and the activation's backward adds to it."""
+        if not self.has_cond:
+            self._activate(inj, c)
+            return
+        self._ce_parts = ops.activate_cond_loss_fwd(c.fake, c.X[:, :self.Dd], self.spans, c.cond, c.mask, self.col2d,
+                                                    self.col2c, self.nd, self.dfake, self.part_loss,
+                                                    exp_noise=inj.get('exp'), rng=self.rng,
+                                                    site=ops.SITE_GUMBEL + self._so, batch_total=self.gB)
 
     def _g_back(self, inj, update, sub):
         self._so = 0 if sub is None else 64 * sub

@@ -211,8 +211,23 @@ def apply_activate_fwd(x, y, spans, exp_noise=None, rng=None, site=SITE_GUMBEL, 
 
 def apply_activate_bwd(y, dy, dx, spans, tau=0.2, accumulate=False):
     lib().call('dpc_apply_activate_bwd', _p(y), _ld(y), _p(dy), _ld(dy), _p(dx), _ld(dx), _p(spans), spans.shape[0],
-               dx.shape[0], tau, int(accumulate), _stream())
+               dx.shape[0], dx.shape[1], tau, int(accumulate), _stream())
     return dx
+
+
+def activate_cond_loss_fwd(x, y, spans, cond, mask, col2d, col2c, nd, dfake, partials, exp_noise=None, rng=None,
+                           site=SITE_GUMBEL, tau=0.2, batch_total=0):
+    """apply_activate_fwd + cond_loss (loss_out None, accumulate False) in one pass over x; returns how many
+    block partials were written."""
+    _chk(mask, torch.int32, 'mask')
+    _chk(partials, torch.float64, 'partials')
+    B, Dd = x.shape
+    n_used = ctypes.c_int(0)
+    lib().call('dpc_activate_cond_loss_fwd', _p(x), _ld(x), _p(y), _ld(y), _p(spans), spans.shape[0], B, Dd,
+               _p(exp_noise), _ld(exp_noise) if exp_noise is not None else 0, _p(rng), site, tau, _p(cond), _ld(cond),
+               _p(mask), _ld(mask), _p(col2d), _p(col2c), nd, int(batch_total), _p(dfake),
+               _ld(dfake) if dfake is not None else 0, _p(partials), partials.numel(), ctypes.byref(n_used), _stream())
+    return n_used.value
 
 
 def cond_loss(fake, cond, mask, col2d, col2c, nd, loss_out, dfake, partials, accumulate=False, batch_total=0):

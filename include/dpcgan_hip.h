@@ -92,10 +92,21 @@ int dpc_gemm_streamk_config(int blocks);
 int dpc_apply_activate_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
                            int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
                            const uint64_t* rng, uint32_t site, float tau, void* stream);
-/* autograd of the above: dx (+)= J^T dy given the saved output y. */
+/* autograd of the above: dx (+)= J^T dy given the saved output y (rows of Dd columns). */
 int dpc_apply_activate_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, float* dx,
-                           int64_t lddx, const int32_t* spans, int nspan, int64_t B, float tau,
+                           int64_t lddx, const int32_t* spans, int nspan, int64_t B, int Dd, float tau,
                            int accumulate, void* stream);
+/* The generator update's two passes over its raw output in one launch: y = _apply_activate(x)
+ * (dp_cgan.py:697, as dpc_apply_activate_fwd) and the conditional loss on the RAW x (dp_cgan.py:711, as
+ * dpc_cond_loss: closed form of _cond_loss_pair): dfake (nullable) is WRITTEN with d loss / d x (zero
+ * outside the discrete columns), partials[0 : *n_used] (fp64, *n_used <= n_partials, host int*) receive
+ * block sums of the un-scaled loss: loss = 2/(B_total*nd) * sum(partials[0 : *n_used]) (dpc_sum_f64). */
+int dpc_activate_cond_loss_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* spans,
+                               int nspan, int64_t B, int Dd, const float* exp_noise, int64_t ld_noise,
+                               const uint64_t* rng, uint32_t site, float tau, const float* cond, int64_t ldc,
+                               const int32_t* mask, int64_t ldm, const int32_t* col2d, const int32_t* col2c,
+                               int nd, int64_t B_total, float* dfake, int64_t lddf, double* partials,
+                               int n_partials, int* n_used, void* stream);
 
 /* ---- conditional loss (DPCGANSynthesizer._cond_loss_pair, dp_cgan.py:330-389), closed form --- */
 /* loss_out[0] = 2/(B*nd) sum_b sum_j mask[b,col2d[j]] * BCEWithLogits(fake[b,j], cond[b,col2c[j]]);

@@ -276,6 +276,71 @@ def test_cond_loss_matches_reference_and_oracle(ops):
         close(dfake, gref, what='d ce / d fake')
 
 
+def test_activation_and_cond_loss_in_one_pass_equal_the_two_kernels(ops):
+    """dpc_activate_cond_loss_fwd = dpc_apply_activate_fwd + dpc_cond_loss on the generator update of the
+    reference trace: identical activations and loss gradient, the loss to the reference's recorded value."""
+    tr = Trace('trace_np.npz')
+    from oracle import nets as onets
+    spans = span_table(tr.span_info).to(dev())
+    col2d, col2c = (t.to(dev()) for t in col_maps(tr.span_info))
+    nd = len(onets.discrete_columns(tr.span_info))
+    s = tr.kinds.index('G')
+    fake = torch.from_numpy(tr.get(s, 'fake')).to(dev())
+    expn = torch.from_numpy(tr.exp_full(s)).to(dev())
+    cond, mask = torch.from_numpy(tr.get(s, 'cond')).to(dev()), torch.from_numpy(tr.get(s, 'mask')).to(dev())
+    part = torch.zeros(2048, dtype=torch.float64, device=dev())
+    y0, y1 = torch.empty_like(fake), torch.empty_like(fake)
+    d0 = torch.full(fake.shape, float('nan'), device=dev())
+    d1 = torch.full(fake.shape, float('nan'), device=dev())
+    loss0 = torch.zeros(1, device=dev())
+    ops.apply_activate_fwd(fake, y0, spans, exp_noise=expn)
+    ops.cond_loss(fake, cond, mask, col2d, col2c, nd, loss0, d0, part)
+    part2 = torch.zeros(2048, dtype=torch.float64, device=dev())
+    for B_total in (0, 4 * tr.B):               # a rank's shard of a global batch scales loss and gradient by B / B_total
+        n = ops.activate_cond_loss_fwd(fake, y1, spans, cond, mask, col2d, col2c, nd, d1, part2, exp_noise=expn,
+                                       batch_total=B_total)
+        k = 1.0 if B_total == 0 else tr.B / B_total
+        assert torch.equal(y0, y1)
+        close(d1, d0 * k, what='loss gradient', rtol=1e-6)
+        loss1 = float(part2[:n].sum()) * 2.0 / ((B_total or tr.B) * nd)
+        close([loss1], [float(tr.get(s, 'ce')) * k], what='ce vs reference')
+        close([loss1], [float(loss0) * k], what='ce vs cond_loss kernel', rtol=1e-6)
+
+
+@pytest.mark.parametrize('Dd_target', [9000, 20000, 40000])
+def test_activation_kernels_on_long_rows(ops, Dd_target):
+    """Rows beyond the 8-row LDS tile: one row per tile (Dd 9000), one row in more than 48 KB of LDS
+    (Dd 20000, TWIDE's width), and the wide-row kernels that work straight from global memory (Dd 40000).
+    Forward and backward against the oracle; Philox path == injected path."""
+    from oracle import nets as onets
+    rng_np = np.random.default_rng(Dd_target)
+    span, Dd = [], 0
+    while Dd < Dd_target:
+        k = int(rng_np.integers(1, 40)) if Dd % 3 else 300
+        if rng_np.random() < 0.2:
+            span.append((1, 0, 2)); Dd += 1
+        span.append((k, 1, 1)); Dd += k
+    span_info = np.array(span, dtype=np.int32)
+    spans = span_table(span_info).to(dev())
+    B = 24
+    x = torch.randn(B, Dd, generator=torch.Generator().manual_seed(1))
+    rng = ops.new_rng(11, dev())
+    e = torch.empty(B, Dd, device=dev())
+    ops.fill(e, ops.FILL_EXP, rng, ops.SITE_GUMBEL)
+    ya, yb = torch.empty(B, Dd, device=dev()), torch.empty(B, Dd, device=dev())
+    ops.apply_activate_fwd(x.to(dev()), ya, spans, rng=rng)
+    ops.apply_activate_fwd(x.to(dev()), yb, spans, exp_noise=e)
+    assert torch.equal(ya, yb)
+    xr = x.clone().requires_grad_(True)
+    yo = onets.apply_activate(xr, span_info, e.cpu())
+    close(ya, yo.detach(), what='forward')
+    dy = torch.randn(B, Dd, generator=torch.Generator().manual_seed(2))
+    (gref,) = torch.autograd.grad(yo, xr, dy)
+    dx = torch.zeros(B, Dd, device=dev())
+    ops.apply_activate_bwd(yo.detach().to(dev()), dy.to(dev()), dx, spans)
+    close(dx, gref, what='backward')
+
+
 # ------------------------------------------------------------------------------------------------
 # sampler
 # ------------------------------------------------------------------------------------------------

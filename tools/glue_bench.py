@@ -1,45 +1,46 @@
-"""Stand-alone timing of the step's glue kernels at the T1M launch sizes (HIP events, 50 reps)."""
+"""Stand-alone timing of the step's non-GEMM kernels at their in-step sizes (T1M, batch 8192): HIP events,
+50 repetitions each, GB/s on the kernel's algorithmic bytes."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dp_cgans_amd import ops
+from dp_cgans_amd.data_sampler import DataSampler
 from dp_cgans_amd.engine import StepEngine
-from dp_cgans_amd.synthetic import schema_span_info
+from dp_cgans_amd.synthetic import build_encoded_table
 
 dev = torch.device('cuda:0')
-span = schema_span_info('T1M')
-eng = StepEngine(span, 128, (256, 256), (256, 256), 8192, 8, dev, private=True, dp_mode='dpsgd')
-B, Dd, n, K0 = eng.B, eng.Dd, eng.n, eng.K0
-x = torch.randn(B, Dd, device=dev)
-y = torch.empty(B, Dd, device=dev)
-dy = torch.randn(B, Dd, device=dev)
-dx = torch.empty(B, Dd, device=dev)
-cond = (torch.rand(B, eng.C, device=dev) < 0.01).float()
-mask = (torch.rand(B, eng.nd, device=dev) < 0.02).int()
+table, span = build_encoded_table('T1M', dev, n_rows=200000)
+eng = StepEngine(span, 128, (256, 256), (256, 256), 8192, 8, dev, private=True, dp_mode='dpsgd', seed=0)
+eng.sampler = DataSampler(table, span, device=dev, seed=1)
+eng.train_step(1)
+torch.cuda.synchronize()
+B, Dd, n = eng.B, eng.Dd, eng.n
 
 
-def timed(name, fn, bytes_):
-    for _ in range(5):
+def timed(name, fn, nbytes, reps=50):
+    for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50):
+    for _ in range(reps):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 20
-    print('%-18s %7.1f us  %6.0f GB/s (algorithmic)' % (name, us, bytes_ / us / 1e3))
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print('%-28s %8.1f us  %7.0f GB/s' % (name, us, nbytes / us / 1e3))
 
 
+c = eng.cg
+x, y = c.fake, c.X[:, :Dd]
+dy = torch.randn(B, Dd, device=dev)
+dx = torch.zeros(B, Dd, device=dev)
 timed('activate_fwd', lambda: ops.apply_activate_fwd(x, y, eng.spans, rng=eng.rng), 8.0 * B * Dd)
+timed('activate_cond_loss_fwd', lambda: ops.activate_cond_loss_fwd(x, y, eng.spans, c.cond, c.mask, eng.col2d, eng.col2c, eng.nd,
+                                                                   dx, eng.part_loss, rng=eng.rng), 4.0 * B * (3 * Dd + eng.nd + eng.C))
 timed('activate_bwd', lambda: ops.apply_activate_bwd(y, dy, dx, eng.spans), 12.0 * B * Dd)
-timed('cond_loss', lambda: ops.cond_loss(x, cond, mask, eng.col2d, eng.col2c, eng.nd, None, dx, eng.part_loss, accumulate=True,
-                                          batch_total=B), 4.0 * B * (2 * Dd + eng.nd))
-timed('interpolate', lambda: ops.interpolate(eng.Xd[B:2 * B], eng.Xd[0:B], eng.Xd[2 * B:3 * B], n, K0, rng=eng.rng), 12.0 * n * K0)
-timed('gp_norm', lambda: ops.gp_norm(eng.Xd3[2 * n:3 * n], 0.01, eng.pen_rows), 8.0 * n * K0)
-z = torch.randn(B, 256, device=dev)
-timed('colreduce<0>', lambda: ops.colreduce_partial(0, z, eng.part), 4.0 * B * 256)
-timed('bn_relu_fwd', lambda: ops.bn_relu_fwd(z, eng.cd.Hg[:, 256:512], eng.cd.bn_mean[0], eng.cd.bn_invstd[0], eng.cd.bn_mean[0],
-                                             eng.cd.bn_mean[0]), 8.0 * B * 256)
-timed('fill z', lambda: ops.fill(eng.cd.Hg[:, 512:640], ops.FILL_NORMAL, eng.rng, 1, 0.0, 1.0), 4.0 * B * 128)
+timed('cond_loss', lambda: ops.cond_loss(x, c.cond, c.mask, eng.col2d, eng.col2c, eng.nd, None, dx, eng.part_loss, accumulate=True,
+                                         batch_total=B), 4.0 * B * (3 * Dd + eng.nd))
+timed('hot_sort', lambda: ops.hot_sort(c.sel, eng.C, c.order, c.sid, c.n_items), 8.0 * 2 * B)
+if len(sys.argv) > 1:
+    sys.exit(0)
