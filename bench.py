@@ -50,12 +50,6 @@ def main():
     from dp_cgans_amd.parallel import Dist
     from dp_cgans_amd.synthetic import build_encoded_table
 
-    if os.environ.get('DPC_STREAMK'):          # tuning experiments: -1 split-K only, 0 automatic stream-K, n forced
-        from dp_cgans_amd._lib import lib
-        lib().cdll.dpc_gemm_streamk_config(int(os.environ['DPC_STREAMK']))
-    if os.environ.get('DPC_GEMM_PF'):          # tuning experiments: prefetch depth of the 64x64 GEMM tile
-        from dp_cgans_amd._lib import lib
-        lib().call('dpc_gemm_prefetch', int(os.environ['DPC_GEMM_PF']))
     dist = Dist()
     if dist.world != args.gpus:
         if args.gpus != 1 or dist.world != 1:

@@ -10,15 +10,21 @@
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 or 64x64), BK = 32,
 // operands staged global -> registers -> LDS (image per operand layout: see Stage), two LDS buffers,
-// the global loads of tile t+PF issued before the MFMAs of tile t (one barrier per K-tile).  Split-K over
-// gridDim.y with fp32 atomics for the weight-gradient shapes (small MxN, K = batch).  Block ids
+// the global loads of tile t+PF issued before the MFMAs of tile t (one barrier per K-tile).  Split-K
+// with fp32 atomics for the weight-gradient shapes (small MxN, K = batch).  Block ids
 // are remapped so that the blocks sharing an A row-panel run on one XCD (private L2).
 #include "dpc_common.h"
+#include "../../include/dpcgan_hip.h"
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native vector type for the staging registers: HIP's float4 is a struct whose copies lower to
 // llvm.memcpy between address spaces, which kept the prefetch ring in scratch memory
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the same with 4-byte alignment for global loads: gfx950 serves a dword-aligned global_load_dwordx4 (hipcc
+// emits one for this type), which is what lets a segment-mapped operand (rows that start at odd offsets,
+// see GemmArgs::seg_*) keep the 16-byte staging path
+typedef f32x4 f32x4u __attribute__((aligned(4)));
 
 #define EPI_NONE 0
 #define EPI_LEAKY_DROPOUT 1
@@ -46,7 +52,20 @@ struct GemmArgs {
   // (negative ids skipped).  It stands for the columns of A that hold a one-/two-hot conditional
   // vector: their product with W^T is the sum of the hot columns of W, i.e. rows of gat = W^T slice.
   const float* gat; int64_t ldg; const int32_t* gidx;
+  // Segment map: index x of a "compact" axis made of segments of seg_pad entries addresses element
+  // (x / seg_pad) * seg_stride + x % seg_pad of the stored axis, of which only the first seg_len entries of a
+  // segment are meaningful.  It lets a product run over the DATA columns of the discriminator's pac-row
+  // layout [pac][Dd data | C cond] (seg_stride = Dd + C, dp_cgan.py:66-68,622-623) without a copy of W1:
+  //   seg_b 1: along K of a k-contiguous B (first layer forward x W1^T; seg_pad % 32 == 0, so a K tile never
+  //            straddles segments);  seg_b 2: along N of an n-contiguous B (input gradient dy W1);
+  //   seg_c 1: along N of C (weight gradient dy^T x into W1's layout; entries beyond seg_len are not stored).
+  int seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
 };
+
+// stored index minus compact index
+__device__ __forceinline__ int64_t gemm_seg_delta(const GemmArgs& g, int x) {
+  return (int64_t)(x / g.seg_pad) * (g.seg_stride - g.seg_pad);
+}
 
 __device__ __forceinline__ float gemm_gather2(const GemmArgs& g, int row, int col) {
   const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
@@ -85,12 +104,12 @@ struct Stage {
     for (int p = 0; p < PASSES; ++p) {
       if (KC) {
         int row = min(mn0 + p * 32 + (t >> 3), MN - 1);
-        r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + k0 + 4 * (t & 7));
+        r[p] = *reinterpret_cast<const f32x4u*>(base + (int64_t)row * ld + k0 + 4 * (t & 7));
       } else {
         constexpr int TPR = BMN / 4;
         constexpr int RPP = 256 / TPR;
         int mn = min(mn0 + 4 * (t % TPR), ((MN + 3) & ~3) - 4);
-        r[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
+        r[p] = *reinterpret_cast<const f32x4u*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
         if (KS) sc[p] = ks[k0 + p * RPP + t / TPR];
       }
     }
@@ -204,6 +223,11 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   // (ld >= extent rounded up to 4) for the last 16-byte load to stay inside its row
   const bool fa = g.a_vec && (A_KC ? g.M >= 1 : (m0 + BM <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
   const bool fb = g.b_vec && (B_KC ? g.N >= 1 : (n0 + BN <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
+  // segment-mapped B: a per-thread offset when the map runs along N (constant over the K loop), a per-K-tile
+  // one (block-uniform: a tile lies inside one segment) when it runs along K
+  const float* Bn = g.B;
+  if (!B_KC && g.seg_b == 2) Bn += gemm_seg_delta(g, min(n0 + 4 * ((int)threadIdx.x % (BN / 4)), ((g.N + 3) & ~3) - 4));
+  auto Bk = [&](int k0) -> const float* { return (B_KC && g.seg_b == 1) ? Bn + gemm_seg_delta(g, k0) : Bn; };
   // PF register stages per operand (a ring indexed by the unrolled tile number: compile-time indices)
   SA sa[PF];
   SB sb[PF];
@@ -267,7 +291,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       sa[j].load_fast(g.A, lda, m0, k_begin + min(j, last) * BK, g.M, g.kscale);
-      sb[j].load_fast(g.B, ldb, n0, k_begin + min(j, last) * BK, g.N);
+      sb[j].load_fast(Bk(k_begin + min(j, last) * BK), ldb, n0, k_begin + min(j, last) * BK, g.N);
     }
     sa[0].store(As0);
     sb[0].store(Bs0);
@@ -278,7 +302,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
         const int cur = u & 1;              // PF is even, so t & 1 == u & 1
         const int tl = min(t0 + u + PF, last);
         sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
-        sb[u].load_fast(g.B, ldb, n0, k_begin + tl * BK, g.N);
+        sb[u].load_fast(Bk(k_begin + tl * BK), ldb, n0, k_begin + tl * BK, g.N);
         compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
         sa[(u + 1) % PF].store(As + (cur ^ 1) * SA::SIZE);
         sb[(u + 1) % PF].store(Bs + (cur ^ 1) * SB::SIZE);
@@ -305,7 +329,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   // Remainder (a partial last tile, or operands the fast path cannot take): one tile at a time.
   for (int t = nfull; t < ntile; ++t) {
     sa[0].load(g.A, lda, m0, k_begin + t * BK, g.M, k_end, fa, g.kscale);
-    sb[0].load(g.B, ldb, n0, k_begin + t * BK, g.N, k_end, fb);
+    sb[0].load(Bk(k_begin + t * BK), ldb, n0, k_begin + t * BK, g.N, k_end, fb);
     sa[0].store(As0);
     sb[0].store(Bs0);
     __syncthreads();
@@ -357,14 +381,21 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   // (One straight-line body per MFMA tile, no `continue`: a loop over the tiles that hipcc does not
   // fully unroll indexes `acc` dynamically and moves all accumulators to scratch memory.)
   auto tile_out = [&](const f32x16& av, const int row0, const int col) {
-    if (col < g.N) {
+    bool live = col < g.N;
+    int64_t ocol = col;                    // column of C in memory
+    if (g.seg_c) {
+      const int sgm = col / g.seg_pad;
+      live = live && (col - sgm * g.seg_pad) < g.seg_len;
+      ocol = col + (int64_t)sgm * (g.seg_stride - g.seg_pad);
+    }
+    if (live) {
       const float bv = (g.bias && add_bias) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row < g.M) {
           float v = g.alpha * av[e] + bv;
-          float* cp = g.C + (int64_t)row * g.ldc + col;
+          float* cp = g.C + (int64_t)row * g.ldc + ocol;
           if (atomic) {
             atomicAdd(cp, v);
           } else {
@@ -435,31 +466,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, split == 0);
 }
 
-// Stream-K kernel (64x64 tiles): the tiles x K-tiles iteration space is cut into gridDim.x equal
-// contiguous runs, one per block, whatever the tile boundaries; a block adds each (partial) tile of
-// its run to C with fp32 atomics.  Every CU gets the same amount of MFMA work and pays the pipeline
-// fill once per block instead of once per tile - the shapes of the training step (48 x 4 tiles of
-// K = 4888, 4 x 11 tiles of K = 8192 ...) never divide evenly over 256 CUs otherwise.
-template <bool A_KC, bool B_KC, int PF, bool KS = false>
-__global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * Stage<64, A_KC, KS>::SIZE + 2 * Stage<64, B_KC>::SIZE];
-  const int ktiles = (g.K + BK - 1) / BK;
-  const int64_t units = (int64_t)g.tiles_m * g.tiles_n * ktiles;
-  const int slot = gemm_xcd_slot(blockIdx.x, gridDim.x);
-  int64_t u = units * slot / gridDim.x;
-  const int64_t u_end = units * (slot + 1) / gridDim.x;
-  while (u < u_end) {
-    const int tile = (int)(u / ktiles);
-    const int kt0 = (int)(u - (int64_t)tile * ktiles);
-    const int kt1 = (int)min((int64_t)ktiles, kt0 + (u_end - u));
-    int tile_m, tile_n;
-    gemm_tile_coords(g, tile, tile_m, tile_n);
-    __syncthreads();                                        // the previous segment's LDS reads are done
-    gemm_segment<64, 64, A_KC, B_KC, PF, KS>(g, lds, tile_m * 64, tile_n * 64, kt0 * BK, min(g.K, kt1 * BK), true, false);
-    u += kt1 - kt0;
-  }
-}
-
 // Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
 __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
   int64_t total = (int64_t)g.M * g.N;
@@ -484,142 +490,94 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
   }
 }
 
-static int g_force_tile = 0;
-static int g_deterministic = 0;
-// Reproducible mode: never split K automatically (split sums are fp32 atomics, whose arrival order
-// changes the last bits from run to run).  Host-side state.
-extern "C" int dpc_set_deterministic(int on) {
-  g_deterministic = on ? 1 : 0;
-  return DPC_OK;
-}
-
-// Tuning / test hook: force the block tile: 0 = automatic, 64 = 64x64, 128 = 128x128,
-// 12864 = 128x64, 64128 = 64x128.
-extern "C" int dpc_gemm_config(int force_tile) {
-  if (force_tile != 0 && force_tile != 64 && force_tile != 128 && force_tile != 12864 && force_tile != 64128)
-    return DPC_EINVAL;
-  g_force_tile = force_tile;
-  return DPC_OK;
-}
-
-static int g_prefetch = 0;
-// Tuning hook: depth of the register prefetch ring of the 64x64 tile: 0 = automatic, 2 or 4.  Host-side state.
-extern "C" int dpc_gemm_prefetch(int depth) {
-  if (depth != 0 && depth != 2 && depth != 4) return DPC_EINVAL;
-  g_prefetch = depth;
-  return DPC_OK;
-}
-
-template <int BM, int BN, int PF>
+template <int BM, int BN>
 static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n * g.splitk), block(256);
   if (g.kscale) {     // validated by the caller: A is m-contiguous
-    if (b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF, true>), grid, block, 0, st, g);
+    if (b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, 2, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, 2, true>), grid, block, 0, st, g);
     return;
   }
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, PF>), grid, block, 0, st, g);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, PF>), grid, block, 0, st, g);
-  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, PF>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, PF>), grid, block, 0, st, g);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, 2>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, 2>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, 2>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, 2>), grid, block, 0, st, g);
 }
 
-template <int PF>
-static void launch_streamk(const GemmArgs& g, bool a_kc, bool b_kc, int nblocks, hipStream_t st) {
-  dim3 grid(nblocks), block(256);
-  if (g.kscale) {
-    if (b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<false, true, PF, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_streamk_kernel<false, false, PF, true>), grid, block, 0, st, g);
-    return;
-  }
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<true, true, PF>), grid, block, 0, st, g);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<true, false, PF>), grid, block, 0, st, g);
-  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<false, true, PF>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_streamk_kernel<false, false, PF>), grid, block, 0, st, g);
-}
-
-// Stream-K is an option, not the default: on the step's shapes it is ~4 % faster than the XCD-aware
-// split-K below (perfect balance) but fetches 2.7x the bytes from beyond L2 - its runs put different
-// K ranges of a panel on an XCD at the same time (G dWout: 268 MB against 59 MB, 41 MB algorithmic).
-static int g_streamk_blocks = -1;    // -1 = never (split-K), 0 = automatic, n = use n blocks whenever allowed
-extern "C" int dpc_gemm_streamk_config(int blocks) {
-  if (blocks < -1 || blocks > 4096) return DPC_EINVAL;
-  g_streamk_blocks = blocks;
-  return DPC_OK;
-}
-
-static int gemm_impl(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
-                     const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
-                     const float* bias, int epi, float* aux_out, int64_t ld_aux_out,
-                     const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
-                     const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
-                     const float* gat, int64_t ldg, const int32_t* gidx, void* stream) {
+// One product.  Every tuning choice travels in the descriptor (splitk, tile): the library keeps no GEMM state.
+static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
+  const int M = d.M, N = d.N, K = d.K;
+  const float beta = d.beta;
+  const int epi = d.epi;
   DPC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return DPC_OK;
-  DPC_CHECK_ARG(!gat || (gidx && ldg >= N && beta == 0.f), "gemm: row gather needs ids, ldg >= N and beta == 0");
-  DPC_CHECK_ARG(A && B && C, "gemm: null operand");
-  DPC_CHECK_ARG(a_rs == 1 || a_cs == 1, "gemm: A needs one unit stride");
-  DPC_CHECK_ARG(b_rs == 1 || b_cs == 1, "gemm: B needs one unit stride");
-  DPC_CHECK_ARG(ldc >= N, "gemm: ldc < N");
+  DPC_CHECK_ARG(!d.gat || (d.gidx && d.ldg >= N && beta == 0.f), "gemm: row gather needs ids, ldg >= N and beta == 0");
+  DPC_CHECK_ARG(!d.gat || epi == EPI_NONE || epi == EPI_RELU, "gemm: row gather goes with epilogue none or ReLU");
+  DPC_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
+  DPC_CHECK_ARG(d.a_rs == 1 || d.a_cs == 1, "gemm: A needs one unit stride");
+  DPC_CHECK_ARG(d.b_rs == 1 || d.b_cs == 1, "gemm: B needs one unit stride");
   DPC_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_RELU, "gemm: unknown epilogue");
-  DPC_CHECK_ARG(epi != EPI_LEAKY_DROPOUT || (aux_out && (keep || rng)), "gemm: dropout epilogue needs slope output and a mask source");
-  DPC_CHECK_ARG(epi != EPI_MUL || aux_in, "gemm: multiply epilogue needs aux_in");
-  hipStream_t st = (hipStream_t)stream;
+  DPC_CHECK_ARG(epi != EPI_LEAKY_DROPOUT || (d.aux_out && (d.keep || d.rng)), "gemm: dropout epilogue needs slope output and a mask source");
+  DPC_CHECK_ARG(epi != EPI_MUL || d.aux_in, "gemm: multiply epilogue needs aux_in");
+  DPC_CHECK_ARG(d.tile == 0 || d.tile == 64 || d.tile == 128, "gemm: tile must be 0 (automatic), 64 or 128");
   GemmArgs g;
-  g.A = A; g.a_rs = a_rs; g.a_cs = a_cs;
-  g.B = B; g.b_rs = b_rs; g.b_cs = b_cs;
-  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-  g.alpha = alpha; g.beta = beta; g.bias = bias; g.epi = epi;
-  g.aux_out = aux_out; g.ld_aux_out = ld_aux_out; g.aux_in = aux_in; g.ld_aux_in = ld_aux_in;
-  g.keep = keep; g.ld_keep = ld_keep; g.rng = rng; g.site = site; g.leak = leak;
+  g.A = d.A; g.a_rs = d.a_rs; g.a_cs = d.a_cs;
+  g.B = d.B; g.b_rs = d.b_rs; g.b_cs = d.b_cs;
+  g.C = d.C; g.ldc = d.ldc; g.M = M; g.N = N; g.K = K;
+  g.alpha = d.alpha; g.beta = beta; g.bias = d.bias; g.epi = epi;
+  g.aux_out = d.aux_out; g.ld_aux_out = d.ld_aux_out; g.aux_in = d.aux_in; g.ld_aux_in = d.ld_aux_in;
+  g.keep = d.keep; g.ld_keep = d.ld_keep; g.rng = d.rng; g.site = d.site; g.leak = d.leak;
   // k-contiguous when the k stride is 1 (ties, e.g. K == 1, go to the k-contiguous path)
-  bool a_kc = (a_cs == 1), b_kc = (b_rs == 1);
-  DPC_CHECK_ARG(!kscale || !a_kc, "gemm: kscale needs an m-contiguous A (the weight-gradient product)");
-  g.kscale = kscale;
-  g.gat = gat; g.ldg = ldg; g.gidx = gidx;
-  int64_t lda = a_kc ? a_rs : a_cs, ldb = b_kc ? b_cs : b_rs;
-  g.a_vec = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
-  g.b_vec = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  DPC_CHECK_ARG(!d.kscale || !a_kc, "gemm: kscale needs an m-contiguous A (the weight-gradient product)");
+  g.kscale = d.kscale;
+  g.gat = d.gat; g.ldg = d.ldg; g.gidx = d.gidx;
+  const int64_t lda = a_kc ? d.a_rs : d.a_cs, ldb = b_kc ? d.b_cs : d.b_rs;
+  g.a_vec = (((uintptr_t)d.A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+  g.b_vec = (((uintptr_t)d.B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  // segment maps (GemmArgs::seg_*)
+  g.seg_b = d.seg_b; g.seg_c = d.seg_c; g.seg_len = d.seg_len; g.seg_pad = d.seg_pad; g.seg_stride = d.seg_stride;
+  if (d.seg_b || d.seg_c) {
+    DPC_CHECK_ARG(d.seg_b >= 0 && d.seg_b <= 2 && (d.seg_c == 0 || d.seg_c == 1), "gemm: unknown segment map");
+    DPC_CHECK_ARG(d.seg_pad > 0 && d.seg_len > 0 && d.seg_len <= d.seg_pad && d.seg_stride >= d.seg_len, "gemm: bad segment map");
+    if (d.seg_b == 1) {
+      DPC_CHECK_ARG(b_kc && d.seg_pad % BK == 0 && K % d.seg_pad == 0, "gemm: a K segment map needs a k-contiguous B, seg_pad % 32 == 0 and K a multiple of seg_pad");
+      DPC_CHECK_ARG((int64_t)(K / d.seg_pad - 1) * d.seg_stride + d.seg_pad <= ldb, "gemm: K segment map runs past B's row");
+      g.b_vec = 1;      // dword-aligned 16-byte loads (f32x4u)
+    } else if (d.seg_b == 2) {
+      DPC_CHECK_ARG(!b_kc && d.seg_pad % 4 == 0 && N % d.seg_pad == 0, "gemm: an N segment map needs an n-contiguous B, seg_pad % 4 == 0 and N a multiple of seg_pad");
+      DPC_CHECK_ARG((int64_t)(N / d.seg_pad - 1) * d.seg_stride + d.seg_pad <= ldb, "gemm: N segment map runs past B's row");
+      g.b_vec = 1;
+    }
+    if (d.seg_c) {
+      DPC_CHECK_ARG(epi == EPI_NONE && !d.bias && !d.gat && N % d.seg_pad == 0, "gemm: a segment-mapped C takes no epilogue, and N a multiple of seg_pad");
+      DPC_CHECK_ARG((int64_t)(N / d.seg_pad - 1) * d.seg_stride + d.seg_len <= d.ldc, "gemm: C segment map runs past ldc");
+      DPC_CHECK_ARG(beta == 1.f, "gemm: a segment-mapped C is accumulated into (beta == 1)");
+    }
+  }
+  DPC_CHECK_ARG(d.seg_c || d.ldc >= N, "gemm: ldc < N");
   // Tile choice (measured per shape with `tools/gemm_bench.py tiles`): the 128x128 tile reaches
   // 120-130 TF/s (~80 % of the fp32 MFMA peak) once the grid holds >= 2 blocks per CU, but every
   // GEMM of the T1M training step (M*N <= 8192*512) is faster on 64x64 tiles, whose 4x as many
-  // blocks fill the 256 CUs; 128x64 / 64x128 never won there and are kept for forced use only.
+  // blocks fill the 256 CUs.
   int bm = 64, bn = 64;
-  if (g_force_tile) {
-    bm = (g_force_tile == 128 || g_force_tile == 12864) ? 128 : 64;
-    bn = (g_force_tile == 128 || g_force_tile == 64128) ? 128 : 64;
-  } else if (dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512) {
-    bm = 128; bn = 128;
-  }
+  if (d.tile == 128 || (d.tile == 0 && dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512)) { bm = 128; bn = 128; }
   g.tiles_m = (int)dpc_cdiv(M, bm);
   g.tiles_n = (int)dpc_cdiv(N, bn);
-  int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
   bool deferred_epi = false;
-  int streamk = 0;                  // > 0: number of blocks of a stream-K launch
+  int splitk = d.splitk;
   if (splitk <= 0) {
     // auto.  Cost model fitted to MI355X measurements of the 64x64 tile (tools/gemm_occupancy.py,
     // tools/gemm_split_sweep.py): a CU works through its resident blocks at 17.5 ns per k and block
     // (21 ns when it holds only one: a single wave per SIMD hides less latency).  One block per tile
-    // spreads `blocks` tiles over 256 CUs - 270 tiles take as long as 512 - while stream-K cuts
-    // tiles x K into equal runs and pays fp32 atomics (~2.5 TB/s, mostly hidden behind other
+    // spreads `blocks` tiles over 256 CUs - 270 tiles take as long as 512 - while split-K cuts each tile's
+    // K range into sp chunks and pays fp32 atomics (~2.5 TB/s, mostly hidden behind other
     // blocks' MFMAs), a memset, and a separate pass for a bias / activation epilogue.
     splitk = 1;
-    const bool can_split = !g_deterministic && (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !bias)) && bm == 64 && bn == 64 && K >= 512;
-    if (can_split && g_streamk_blocks >= 0) {
-      const bool deferred = (epi != EPI_NONE || bias || gat);
-      const double nb = (double)blocks;
-      const double c = nb <= 256.0 ? 1.0 : (nb <= 768.0 ? (double)dpc_cdiv(blocks, 256) : nb / 256.0 + 0.3);
-      const double t_plain = c * ((double)K * (nb <= 256.0 ? 0.021 : 0.0175) + 1.0) + 6.0;
-      const double kblocks = nb * (double)dpc_cdiv(K, BK) * BK;          // k per block summed over all tiles
-      // measured (tools/gemm_streamk_sweep.py): few tiles -> one block per CU, else 2-3 per CU
-      const int sk_blocks = blocks < 64 ? 256 : (kblocks >= 768.0 * 256.0 ? 768 : (kblocks >= 512.0 * 128.0 ? 512 : 256));
-      const double t_sk = kblocks / 256.0 * (sk_blocks > 256 ? 0.0175 : 0.021) + 3.0 + 6.0 +
-                          (double)M * N * 4.0 * (1.0 + sk_blocks / nb) / 2.5e6 + (beta == 0.f ? 4.0 : 0.0) + (deferred ? 6.0 : 0.0);
-      if (g_streamk_blocks > 0) streamk = g_streamk_blocks;
-      else if (t_sk < 0.95 * t_plain) streamk = sk_blocks;
-    } else if (can_split) {
-      // split-K: tiles x sp blocks, each tile's K range cut into sp equal chunks
-      const bool deferred = (epi != EPI_NONE || bias || gat);
+    const bool can_split = (beta == 0.f || (beta == 1.f && epi == EPI_NONE && !d.bias)) && bm == 64 && bn == 64 && K >= 512;
+    if (can_split) {
+      const bool deferred = (epi != EPI_NONE || d.bias || d.gat);
       double best = 1e30;
       int64_t maxs = K / 256;
       if (maxs > 32) maxs = 32;
@@ -633,37 +591,51 @@ static int gemm_impl(int M, int N, int K, float alpha, const float* A, int64_t a
       }
     }
   }
-  if (splitk > 1 && (epi != EPI_NONE || bias || gat)) {
-    DPC_CHECK_ARG(beta == 0.f, "gemm: split-K with an epilogue needs beta == 0");
-    deferred_epi = true;
+  if (splitk > 1) {
+    DPC_CHECK_ARG(bm == 64 && bn == 64, "gemm: split-K runs on the 64x64 tile");
+    DPC_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: split-K needs beta in {0,1}");
+    if (epi != EPI_NONE || d.bias || d.gat) {
+      DPC_CHECK_ARG(beta == 0.f, "gemm: split-K with an epilogue needs beta == 0");
+      deferred_epi = true;
+    }
   }
-  if (streamk > 0 && (epi != EPI_NONE || bias || gat)) deferred_epi = true;
-  DPC_CHECK_ARG(splitk == 1 || beta == 0.f || beta == 1.f, "gemm: split-K needs beta in {0,1}");
   g.splitk = splitk;
-  int ktiles = (int)dpc_cdiv(K, BK);
+  const int ktiles = (int)dpc_cdiv(K, BK);
   g.kchunk = (int)dpc_cdiv(ktiles, splitk) * BK;
   if (K == 0) g.kchunk = BK;
-  if ((splitk > 1 || streamk > 0) && beta == 0.f) {
-    hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+  if (splitk > 1 && beta == 0.f) {
+    hipError_t e = hipMemset2DAsync(d.C, d.ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
     if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
     g.beta = 1.f;   // accumulate into the zeroed C
   }
   GemmArgs full = g;
   if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; g.gat = nullptr; }
-  if (streamk > 0) {
-    int64_t units = blocks * ktiles;
-    if (streamk > units) streamk = (int)units;
-    launch_streamk<2>(g, a_kc, b_kc, streamk, st);
-  }
-  else if (bm == 128 && bn == 128) launch_tile<128, 128, 2>(g, a_kc, b_kc, st);
-  else if (bm == 128) launch_tile<128, 64, 2>(g, a_kc, b_kc, st);
-  else if (bn == 128) launch_tile<64, 128, 2>(g, a_kc, b_kc, st);
-  else if (g_prefetch == 4) launch_tile<64, 64, 4>(g, a_kc, b_kc, st);
-  else launch_tile<64, 64, 2>(g, a_kc, b_kc, st);
+  if (bm == 128) launch_tile<128, 128>(g, a_kc, b_kc, st);
+  else launch_tile<64, 64>(g, a_kc, b_kc, st);
   if (deferred_epi)
     hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(dpc_grid((int64_t)M * N, 256)), dim3(256), 0, st, full);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
+}
+
+// The GEMM entry point: `count` products described by `d[0 .. count)` (host memory), issued in order on `stream`.
+extern "C" int dpc_gemm_f32_ex(const dpc_gemm_desc* d, int count, void* stream) {
+  DPC_CHECK_ARG(d && count >= 1 && count <= 64, "gemm_ex: 1..64 descriptors");
+  for (int i = 0; i < count; ++i) {
+    int rc = gemm_one(d[i], (hipStream_t)stream);
+    if (rc != DPC_OK) return rc;
+  }
+  return DPC_OK;
+}
+
+static dpc_gemm_desc gemm_plain_desc(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                                     const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                                     const float* bias, int epi) {
+  dpc_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta; d.A = A; d.a_rs = a_rs; d.a_cs = a_cs; d.B = B; d.b_rs = b_rs;
+  d.b_cs = b_cs; d.C = C; d.ldc = ldc; d.bias = bias; d.epi = epi; d.leak = 0.2f;
+  return d;
 }
 
 extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
@@ -672,8 +644,10 @@ extern "C" int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, in
                             const float* aux_in, int64_t ld_aux_in, const uint8_t* keep, int64_t ld_keep,
                             const uint64_t* rng, uint32_t site, float leak, int splitk, const float* kscale,
                             void* stream) {
-  return gemm_impl(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, epi, aux_out, ld_aux_out, aux_in,
-                   ld_aux_in, keep, ld_keep, rng, site, leak, splitk, kscale, nullptr, 0, nullptr, stream);
+  dpc_gemm_desc d = gemm_plain_desc(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, epi);
+  d.aux_out = aux_out; d.ld_aux_out = ld_aux_out; d.aux_in = aux_in; d.ld_aux_in = ld_aux_in; d.keep = keep;
+  d.ld_keep = ld_keep; d.rng = rng; d.site = site; d.leak = leak; d.splitk = splitk; d.kscale = kscale;
+  return gemm_one(d, (hipStream_t)stream);
 }
 
 // Linear over an input whose trailing columns are a one-/two-hot conditional vector (the generator's
@@ -684,7 +658,7 @@ extern "C" int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float
                                    const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, const float* bias,
                                    int epi, const float* gat, int64_t ldg, const int32_t* gidx, void* stream) {
   DPC_CHECK_ARG(gat && gidx, "gemm_gather: null pointer");
-  DPC_CHECK_ARG(epi == EPI_NONE || epi == EPI_RELU, "gemm_gather: epilogue must be none or ReLU");
-  return gemm_impl(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, 0.f, C, ldc, bias, epi, nullptr, 0, nullptr, 0, nullptr, 0,
-                   nullptr, 0, 0.2f, 0, nullptr, gat, ldg, gidx, stream);
+  dpc_gemm_desc d = gemm_plain_desc(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, 0.f, C, ldc, bias, epi);
+  d.gat = gat; d.ldg = ldg; d.gidx = gidx;
+  return gemm_one(d, (hipStream_t)stream);
 }

@@ -151,7 +151,7 @@ class StepEngine(object):
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
                  private=False, seed=None, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
-                 weight_clip=None, gp_gram=None, sparse_cond=None):
+                 weight_clip=None, gp_gram=None, sparse_cond=None, deterministic=None):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
         if seed is None:
@@ -184,6 +184,8 @@ class StepEngine(object):
         if weight_clip is None:
             weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
         self.weight_clip = float(weight_clip)
+        # bit-reproducible steps (no split-K atomics, no scatter atomics): read once from the process default
+        self.deterministic = bool(ops.DETERMINISTIC) if deterministic is None else bool(deterministic)
         self._ar_hook = None
         self._early_hook = None
         self._inline = False
@@ -348,6 +350,15 @@ class StepEngine(object):
             self.disc.P('seq.%d.weight' % (3 * i)).copy_(w)
             self.disc.P('seq.%d.bias' % (3 * i)).copy_(b)
 
+    def _mm(self, A, B, C, **kw):
+        """A GEMM of this engine: split-K (fp32 atomics) only when the engine is not in reproducible mode."""
+        kw.setdefault('splitk', 1 if self.deterministic else 0)
+        return ops.gemm(A, B, C, **kw)
+
+    def _mm_gather(self, A, B, C, gat, gidx, **kw):
+        kw.setdefault('splitk', 1 if self.deterministic else 0)
+        return ops.gemm_gather(A, B, C, gat, gidx, **kw)
+
     # buffers of the latest update's generator forward (the tests and the samplers' checks read them)
     Hg = property(lambda self: self._last.Hg)
     fake = property(lambda self: self._last.fake)
@@ -470,7 +481,7 @@ class StepEngine(object):
                 # W1 W1^T of the Gram-form penalty (see _d_back): issued here, beside the generator forward's
                 # chain of small kernels, rather than beside the discriminator's first-layer product
                 W1 = self.disc.P('seq.0.weight')
-                ops.gemm(W1, W1, self.G1, trans_b=True)
+                self._mm(W1, W1, self.G1, trans_b=True)
                 self._g1_issued = True
 
     def _gen_weight(self, l):
@@ -486,12 +497,12 @@ class StepEngine(object):
         """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear)."""
         W = self._gen_weight(l)
         if not self.sparse_cond:
-            ops.gemm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias)
+            self._mm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias)
             return
         if self._wct_stale or self.gen.loaded:       # parameters were (re)loaded outside an optimiser step
             self.gen.loaded = False
             self._refresh_wct()
-        ops.gemm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
+        self._mm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
                         bias=bias)
 
     def _gen_dweight(self, c, l, dy, part, what=3):
@@ -499,13 +510,13 @@ class StepEngine(object):
         dense input columns; & 2: the cond columns' row sums and the bias gradient)."""
         gw = self.gen.G('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
         gb = self.gen.G('seq.%d.fc.bias' % l if l < self.L else 'seq.%d.bias' % self.L)
-        if self.sparse_cond and not ops.DETERMINISTIC:
+        if self.sparse_cond and not self.deterministic:
             if what & 1:
-                ops.gemm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
+                self._mm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
             if what & 2:
                 ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
         elif what & 1:
-            ops.gemm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
+            self._mm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
         if what & 2:
             self._colsum(dy, gb.view(1, -1), part=part)
 
@@ -644,14 +655,14 @@ class StepEngine(object):
             # K0-long first product into the all-zero Zp (see _disc_forward_stacked: no memset node), then
             # bias + LeakyReLU + Dropout in the pass that clears Zp again
             zp = self.Zp[0:rows]
-            ops.gemm(x, d.P('seq.0.weight'), zp, trans_b=True, beta=1.0)
+            self._mm(x, d.P('seq.0.weight'), zp, trans_b=True, beta=1.0)
             ops.disc_first_layer_act(zp, d.P('seq.0.bias'), rows, self.H[0][rs], self.S[0][rs],
                                      keep=keeps[0] if keeps else None, rng=self.rng, site_keep=ops.SITE_DROP0 + self._so,
                                      leak=LEAK, stacked=False, clear=True)
             x = self.H[0][rs]
             first = 1
         for i in range(first, M):
-            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
+            self._mm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
                      rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
             x = self.H[i][rs]
@@ -671,14 +682,14 @@ class StepEngine(object):
         # Zp is all zero here (allocated so; its last reader - the activation pass, or the per-example Gram
         # kernel in DP-SGD mode - clears what it reads): the K0-long product
         # runs split-K with its atomics adding straight into it, no memset node in front
-        ops.gemm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True, beta=1.0)
+        self._mm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True, beta=1.0)
         keeps = inj.get('keep')
         ops.disc_first_layer_act(self.Zp, d.P('seq.0.bias'), n, self.H[0], self.S[0], alpha_inj=inj.get('alpha'),
                                  keep=keeps[0] if keeps else None, rng=self.rng, site_alpha=ops.SITE_ALPHA + self._so,
                                  site_keep=ops.SITE_DROP0 + self._so, leak=LEAK, clear=self.dp_mode != 'dpsgd')
         x = self.H[0]
         for i in range(1, M):
-            ops.gemm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
+            self._mm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i], keep=keeps[i] if keeps else None,
                      rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
             x = self.H[i]
@@ -710,7 +721,7 @@ class StepEngine(object):
         """D_M = rowscale * w_last * S_M;  D_{i-1} = (D_i W_i) * S_{i-1}."""
         d, M = self.disc, self.M       # (the seed D_M was written by the head kernel of _disc_forward)
         for i in range(M - 1, 0, -1):
-            ops.gemm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
+            self._mm(self.Dl[i][0:rows], d.P('seq.%d.weight' % (3 * i)), self.Dl[i - 1][0:rows], epi=ops.EPI_MUL,
                      aux_in=self.S[i - 1][0:rows])
 
     class _Fork(object):
@@ -797,7 +808,7 @@ class StepEngine(object):
             # shrink from 3n to 2n rows (forward, weight gradient) or disappear (g0, v1).
             if not self._g1_issued:
                 with self._fork(0):
-                    ops.gemm(W1, W1, self.G1, trans_b=True)
+                    self._mm(W1, W1, self.G1, trans_b=True)
             self._g1_issued = False
             self._disc_forward_stacked(inj)
         else:
@@ -813,15 +824,15 @@ class StepEngine(object):
         # factors: v_i = (v_{i-1} W_i^T) * S_i over the penalty rows, stored where H_i's xhat rows were
         if gram:
             self._join()
-            ops.gemm(self.Dl[0][gp_rows], self.G1, self.Tq)
+            self._mm(self.Dl[0][gp_rows], self.G1, self.Tq)
             ops.gp_gram_rows(self.Tq, self.Dl[0][gp_rows], self.S[0][gp_rows], coef, self.pen_rows, self.gp_f,
                              self.H[0][gp_rows], q_out=self.gp_q)
         else:
-            ops.gemm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
+            self._mm(self.Dl[0][gp_rows], W1, self.Xd3[gp_rows])                    # g0 = u1 W1 over the xhat rows
             ops.gp_norm(self.Xd3[gp_rows], coef, self.pen_rows)                     # -> v0 in place
-            ops.gemm(self.Xd3[gp_rows], W1, self.H[0][gp_rows], trans_b=True, epi=ops.EPI_MUL, aux_in=self.S[0][gp_rows])
+            self._mm(self.Xd3[gp_rows], W1, self.H[0][gp_rows], trans_b=True, epi=ops.EPI_MUL, aux_in=self.S[0][gp_rows])
         for i in range(1, M):
-            ops.gemm(self.H[i - 1][gp_rows], d.P('seq.%d.weight' % (3 * i)), self.H[i][gp_rows], trans_b=True,
+            self._mm(self.H[i - 1][gp_rows], d.P('seq.%d.weight' % (3 * i)), self.H[i][gp_rows], trans_b=True,
                      epi=ops.EPI_MUL, aux_in=self.S[i][gp_rows])
         kscale, w_last, w_bias, pen_scale = None, self.rowscale_d, None, self.gp_f
         if self.dp_mode == 'dpsgd':
@@ -845,7 +856,7 @@ class StepEngine(object):
         with self._fork(0) as part:
             prev = self.H[0]
             for i in range(1, M):
-                ops.gemm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
+                self._mm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
                 self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1), w=w_bias, part=part)
                 prev = self.H[i]
         with self._fork(1) as part:
@@ -855,13 +866,13 @@ class StepEngine(object):
         if gram:
             # penalty part (u^T diag(f c) u) W1 fills the gradient, the fake and real rows' product adds to it
             u = self.Dl[0][gp_rows]
-            ops.gemm(u, u, self.P1, trans_a=True, kscale=pen_scale)
-            ops.gemm(self.P1, W1, d.G('seq.0.weight'))
-            ops.gemm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
+            self._mm(u, u, self.P1, trans_a=True, kscale=pen_scale)
+            self._mm(self.P1, W1, d.G('seq.0.weight'))
+            self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
                      kscale=kscale[0:2 * n] if kscale is not None else None)
         else:
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
-            ops.gemm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
+            self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
         self._join()
         if update:
             self._disc_update(inj)
@@ -933,14 +944,14 @@ class StepEngine(object):
         self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3)
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
-        ops.gemm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
+        self._mm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
         ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans, accumulate=self.has_cond)
         # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
         if hid > 0:
-            ops.gemm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
+            self._mm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
         self._join()     # branches still open from the front half (the hot-id sort, deferred running statistics)
         # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
@@ -962,7 +973,7 @@ class StepEngine(object):
             Wl = g.P('seq.%d.fc.weight' % l)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
-                ops.gemm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
+                self._mm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
             if l == 0:
                 # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
                 # bias gradient while the product runs beside it
@@ -973,7 +984,7 @@ class StepEngine(object):
                 with self._fork((L - l) % 2) as part:           # after the chain's product, as above
                     self._gen_dweight(c, l, self.dZ[l], part)
         self._join()
-        if self.sparse_cond and not ops.DETERMINISTIC:
+        if self.sparse_cond and not self.deterministic:
             # the scattered cond-column gradients into their places in the flat gradient buffer
             ops.transpose_slices([(self.dWcT[l], self.gen.G('seq.%d.fc.weight' % l if l < L else 'seq.%d.weight' % L)[:, -self.C:])
                                   for l in range(L + 1)])

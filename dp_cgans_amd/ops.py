@@ -69,10 +69,35 @@ DETERMINISTIC = False
 
 
 def set_deterministic(on=True):
-    """Bit-reproducible steps (no split-K atomics in the GEMMs, no scatter atomics), at some cost in speed."""
+    """Process-wide DEFAULT for bit-reproducible steps (no split-K atomics in the GEMMs, no scatter atomics), at
+    some cost in speed.  It is a Python-side default only: the library keeps no state, every GEMM call carries
+    its own ``splitk`` (a StepEngine reads the default once, when it is built)."""
     global DETERMINISTIC
-    lib().call('dpc_set_deterministic', int(bool(on)))
     DETERMINISTIC = bool(on)
+
+
+class GemmDesc(ctypes.Structure):
+    """dpc_gemm_desc of include/dpcgan_hip.h."""
+    _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('alpha', ctypes.c_float), ('beta', ctypes.c_float),
+                ('A', ctypes.c_void_p), ('a_rs', ctypes.c_int64), ('a_cs', ctypes.c_int64),
+                ('B', ctypes.c_void_p), ('b_rs', ctypes.c_int64), ('b_cs', ctypes.c_int64),
+                ('C', ctypes.c_void_p), ('ldc', ctypes.c_int64),
+                ('bias', ctypes.c_void_p), ('epi', ctypes.c_int32), ('leak', ctypes.c_float),
+                ('aux_out', ctypes.c_void_p), ('ld_aux_out', ctypes.c_int64),
+                ('aux_in', ctypes.c_void_p), ('ld_aux_in', ctypes.c_int64),
+                ('keep', ctypes.c_void_p), ('ld_keep', ctypes.c_int64),
+                ('rng', ctypes.c_void_p), ('site', ctypes.c_uint32),
+                ('splitk', ctypes.c_int32), ('tile', ctypes.c_int32),
+                ('kscale', ctypes.c_void_p),
+                ('gat', ctypes.c_void_p), ('ldg', ctypes.c_int64), ('gidx', ctypes.c_void_p),
+                ('seg_b', ctypes.c_int32), ('seg_c', ctypes.c_int32), ('seg_len', ctypes.c_int32),
+                ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64)]
+
+
+def _addr(t):
+    p = _p(t)
+    return None if p is None else p.value
 
 
 def new_rng(seed, device):
@@ -101,58 +126,81 @@ def _mat_strides(t, trans):
     return (cs, rs) if trans else (rs, cs)
 
 
-def gemm(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
-         aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=0, kscale=None):
-    """C = epi(alpha * op(A) @ op(B) + bias) + beta * C on the matrix cores (fp32 MFMA)."""
-    for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (aux_out, 'aux_out'), (aux_in, 'aux_in')):
+def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
+              aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
+              seg_b=0, seg_c=0, seg=None):
+    """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
+    ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
+    n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
+    (B) - the tensor passed for the mapped operand is the stored one, only its base pointer and leading
+    dimension are used."""
+    for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (aux_out, 'aux_out'), (aux_in, 'aux_in'), (gat, 'gat')):
         _chk(t, torch.float32, n)
     _chk(keep, torch.uint8, 'keep')
     _chk(kscale, torch.float32, 'kscale')
+    _chk(gidx, torch.int32, 'gidx')
     a_rs, a_cs = _mat_strides(A, trans_a)
     b_rs, b_cs = _mat_strides(B, trans_b)
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
     K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
-    if K != K2 or C.shape[0] != M or C.shape[1] != N:
+    if seg_b == 1:          # B's K axis is the stored (longer) one
+        K2 = K
+    elif seg_b == 2:        # B's N axis is the stored one; C is compact
+        N = C.shape[1]
+    if seg_c:               # C's N axis is the stored one; B is compact
+        if K != K2 or C.shape[0] != M:
+            raise ValueError('gemm shape mismatch (segment-mapped C)')
+    elif K != K2 or C.shape[0] != M or C.shape[1] != N:
         raise ValueError('gemm shape mismatch: op(A) %dx%d, op(B) %dx%d, C %s' % (M, K, K2, N, tuple(C.shape)))
+    if gat is not None and (gat.shape[1] != N or gidx.shape[0] != M or gidx.shape[1] != 2 or not gidx.is_contiguous()):
+        raise ValueError('gemm: gat must be [ids, N], gidx a contiguous [M, 2]')
+    if splitk is None:
+        splitk = 1 if DETERMINISTIC else 0
+    d = GemmDesc()
+    d.M, d.N, d.K, d.alpha, d.beta = M, N, K, alpha, beta
+    d.A, d.a_rs, d.a_cs = _addr(A), a_rs, a_cs
+    d.B, d.b_rs, d.b_cs = _addr(B), b_rs, b_cs
+    d.C, d.ldc = _addr(C), _ld(C)
+    d.bias, d.epi, d.leak = _addr(bias), epi, leak
+    d.aux_out, d.ld_aux_out = _addr(aux_out), _ld(aux_out) if aux_out is not None else 0
+    d.aux_in, d.ld_aux_in = _addr(aux_in), _ld(aux_in) if aux_in is not None else 0
+    d.keep, d.ld_keep = _addr(keep), _ld(keep) if keep is not None else 0
+    d.rng, d.site, d.splitk, d.tile, d.kscale = _addr(rng), site, int(splitk), int(tile), _addr(kscale)
+    d.gat, d.ldg, d.gidx = _addr(gat), _ld(gat) if gat is not None else 0, _addr(gidx)
+    if seg is not None:
+        d.seg_b, d.seg_c = int(seg_b), int(seg_c)
+        d.seg_len, d.seg_pad, d.seg_stride = int(seg[0]), int(seg[1]), int(seg[2])
+    d._flops = 2.0 * M * N * K
+    d._shape = (M, N, K, trans_a, trans_b)
+    return d
+
+
+def gemm_run(descs):
+    """Issue the products of ``descs`` (list of gemm_desc results) in order with ONE library call."""
+    n = len(descs)
+    arr = (GemmDesc * n)(*descs)
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    args = ('dpc_gemm_f32', M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, beta, _p(C), _ld(C), _p(bias),
-            epi, _p(aux_out), _ld(aux_out) if aux_out is not None else 0, _p(aux_in),
-            _ld(aux_in) if aux_in is not None else 0, _p(keep), _ld(keep) if keep is not None else 0, _p(rng),
-            site, leak, splitk, _p(kscale))
-    lib().call(*args, _stream())
+    st = _stream()
+    lib().call('dpc_gemm_f32_ex', ctypes.byref(arr), n, st)
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, trans_a, trans_b), lambda: lib().call(*args, _stream())))
+        prof.append((e0, e1, sum(d._flops for d in descs), descs[0]._shape,
+                     lambda: lib().call('dpc_gemm_f32_ex', ctypes.byref(arr), n, _stream())))
+
+
+def gemm(A, B, C, **kw):
+    """C = epi(alpha * op(A) @ op(B) + bias) + beta * C on the matrix cores (fp32 MFMA); keywords of gemm_desc."""
+    gemm_run([gemm_desc(A, B, C, **kw)])
     return C
 
 
-def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE):
+def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE, splitk=None):
     """C = epi(A @ op(B) + bias + gat[gidx[:,0]] + gat[gidx[:,1]]) (ids < 0 skipped): Linear over the dense
     columns of an input whose trailing cond columns are one-/two-hot; gat = W[:, cond columns]^T."""
-    for t, n in ((A, 'A'), (B, 'B'), (C, 'C'), (bias, 'bias'), (gat, 'gat')):
-        _chk(t, torch.float32, n)
-    _chk(gidx, torch.int32, 'gidx')
-    a_rs, a_cs = _mat_strides(A, False)
-    b_rs, b_cs = _mat_strides(B, trans_b)
-    M, K = A.shape
-    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
-    if K != K2 or C.shape[0] != M or C.shape[1] != N or gat.shape[1] != N or gidx.shape[0] != M or gidx.shape[1] != 2:
-        raise ValueError('gemm_gather shape mismatch')
-    if not gidx.is_contiguous():
-        raise ValueError('gemm_gather: gidx must be contiguous [M, 2]')
-    prof = GEMM_PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    args = ('dpc_gemm_f32_gather', M, N, K, 1.0, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs, _p(C), _ld(C), _p(bias), epi,
-            _p(gat), _ld(gat), _p(gidx))
-    lib().call(*args, _stream())
-    if prof is not None:
-        e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, False, trans_b), lambda: lib().call(*args, _stream())))
+    gemm_run([gemm_desc(A, B, C, trans_b=trans_b, bias=bias, epi=epi, gat=gat, gidx=gidx, splitk=splitk)])
     return C
 
 

@@ -52,8 +52,8 @@ int dpc_fill(void* out, int kind, int64_t ld, int64_t rows, int64_t cols, const 
 /* C = epi(alpha * A.B + bias) + beta*C.  A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs];
  * one stride of each must be 1.  epi: 0 none; 1 bias+LeakyReLU(leak)+Dropout(0.5): writes
  * slope = (pre>0 ? 1 : leak)*keep*2 to aux_out and C = pre*slope (keep from `keep` u8 [M,N] or
- * Philox idx m*N+n); 2 multiply by aux_in[m,n]; 3 ReLU.  splitk 0 = automatic (fp32 atomics,
- * only for epi 0 and beta in {0,1}).  kscale (nullable, needs an m-contiguous A, i.e. the
+ * Philox idx m*N+n); 2 multiply by aux_in[m,n]; 3 ReLU.  splitk 0 = automatic (fp32 atomics; beta in
+ * {0,1}), 1 = never (bit-reproducible).  kscale (nullable, needs an m-contiguous A, i.e. the
  * weight-gradient product dW = dY^T X): A(m,k) is multiplied by kscale[k] while it is staged, which
  * fuses the DP-SGD clip factor of row k into the gradient sum (clip-scale-sum). */
 int dpc_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
@@ -72,19 +72,39 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
                         const float* bias, int epi, const float* gat, int64_t ldg, const int32_t* gidx,
                         void* stream);
 
-/* tuning / test hook: force the GEMM block tile (0 automatic, 64 = 64x64, 128 = 128x128,
- * 12864 = 128x64, 64128 = 64x128).  Host-side state. */
-int dpc_gemm_config(int force_tile);
-/* tuning hook: depth of the 64x64 tile's register prefetch ring (0 automatic, 2, 4).  Host-side state. */
-int dpc_gemm_prefetch(int depth);
-/* reproducible mode: no automatic split-K (its fp32 atomics make the last bits order-dependent);
- * every other kernel of the library is bit-reproducible already.  Host-side state. */
-int dpc_set_deterministic(int on);
-/* Large-K products with few tiles are cut along K (fp32 atomics; not in deterministic mode, beta in
- * {0,1}).  -1 (initial state): split-K, tiles x s blocks in an XCD-aware order (HBM traffic ~1.2x the
- * algorithmic bytes); 0: stream-K chosen automatically (equal runs of tiles x K per block, ~4 % faster,
- * 2.7x the traffic); n > 0: stream-K with n blocks.  Host-side state. */
-int dpc_gemm_streamk_config(int blocks);
+/* One GEMM in full: what dpc_gemm_f32 / dpc_gemm_f32_gather take, plus the per-call choices that used to
+ * be library state and the segment maps.  Zero-fill it, then set what the product needs.
+ *   splitk  0 automatic, 1 never (no fp32 atomics: bit-reproducible results), n > 1 forced;
+ *   tile    0 automatic, 64 (64x64 block tile) or 128 (128x128);
+ *   gat / ldg / gidx  the row gather of dpc_gemm_f32_gather;
+ *   seg_*   segment map: index x of a compact axis made of segments of seg_pad entries addresses element
+ *           (x / seg_pad) * seg_stride + x % seg_pad of the stored axis, the first seg_len entries of a
+ *           segment being meaningful.  It runs a product over the DATA columns of the discriminator's
+ *           pac-row layout [pac][Dd data | C cond] (seg_stride = Dd + C; dp_cgan.py:66-68, 622-623) in place:
+ *           seg_b 1 = along K of a k-contiguous B (x W1^T; seg_pad % 32 == 0), seg_b 2 = along N of an
+ *           n-contiguous B (dy W1; seg_pad % 4 == 0), seg_c 1 = along N of C (dy^T x accumulated into W1's
+ *           layout, beta == 1; columns beyond seg_len of a segment are not stored). */
+typedef struct dpc_gemm_desc {
+  int32_t M, N, K;
+  float alpha, beta;
+  const float* A; int64_t a_rs, a_cs;
+  const float* B; int64_t b_rs, b_cs;
+  float* C; int64_t ldc;
+  const float* bias;
+  int32_t epi;
+  float leak;
+  float* aux_out; int64_t ld_aux_out;
+  const float* aux_in; int64_t ld_aux_in;
+  const uint8_t* keep; int64_t ld_keep;
+  const uint64_t* rng; uint32_t site;
+  int32_t splitk, tile;
+  const float* kscale;
+  const float* gat; int64_t ldg; const int32_t* gidx;
+  int32_t seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
+} dpc_gemm_desc;
+/* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
+ * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */
+int dpc_gemm_f32_ex(const dpc_gemm_desc* d, int count, void* stream);
 
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
 /* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)

@@ -107,6 +107,54 @@ def test_gemm_epilogues(ops):
     close(H, (X.double() @ W.double().t()) * Mul.double(), what='mul epilogue')
 
 
+@pytest.mark.parametrize('n,pac,Dd,C,d0', [(64, 8, 335, 276, 256), (10, 10, 56, 38, 128), (37, 3, 40, 30, 21), (1024, 8, 335, 276, 256)])
+def test_gemm_segment_maps_run_over_the_data_columns_of_the_pac_row_layout(ops, n, pac, Dd, C, d0):
+    """The three products of the discriminator's first layer over the DATA columns of its pac-row input
+    [pac][Dd data | C cond] with W1 left in the reference's layout (dp_cgan.py:66-68, 622-623): forward
+    x W1^T (K segments on B), input gradient dy W1 (N segments on B), weight gradient dy^T x (N segments
+    on C, accumulated) - each against the dense fp64 product over the data columns."""
+    g = torch.Generator().manual_seed(n + Dd)
+    d_ = dev()
+    row, P = Dd + C, (Dd + 31) // 32 * 32
+    K0, Kc = pac * row, pac * P
+    W1 = (torch.randn(d0, K0, generator=g) / K0 ** 0.5)
+    W1d = torch.randn(d0, (K0 + 3) // 4 * 4, generator=g)[:, :K0].to(d_)           # rows padded to 16 bytes, as the engine's are
+    W1d.copy_(W1)
+    xd = torch.randn(n, pac, Dd, generator=g)
+    xc = torch.zeros(n, pac, P)
+    xc[:, :, :Dd] = xd                                                                # compact rows: zero padding
+    Xc = xc.reshape(n, Kc).to(d_)
+    W1data = W1.reshape(d0, pac, row)[:, :, :Dd]                                     # [d0, pac, Dd]
+    seg = (Dd, P, row)
+    # forward
+    ref = torch.einsum('rsj,osj->ro', xd.double(), W1data.double())
+    for splitk in (1, 0):
+        out = torch.zeros(n, d0, device=d_)
+        ops.gemm(Xc, W1d, out, trans_b=True, beta=1.0, seg_b=1, seg=seg, splitk=splitk)
+        close(out, ref, what='forward over data columns (splitk %d)' % splitk)
+    # input gradient (compact output; the padding columns hold products with cond weights and are never read)
+    dy = torch.randn(n, d0, generator=g)
+    dX = torch.full((n, Kc), float('nan'), device=d_)
+    ops.gemm(dy.to(d_), W1d, dX, seg_b=2, seg=seg)
+    ref = torch.einsum('ro,osj->rsj', dy.double(), W1data.double())
+    close(dX.view(n, pac, P)[:, :, :Dd], ref, what='input gradient over data columns')
+    # weight gradient accumulated into W1's layout: data columns get dy^T x added, cond columns stay
+    base = torch.randn(d0, K0, generator=g)
+    ks = torch.rand(n, generator=g)
+    for splitk in (1, 0):
+        dW = torch.empty_like(W1d)
+        dW.copy_(base)
+        ops.gemm(dy.to(d_), Xc, dW, trans_a=True, beta=1.0, seg_c=1, seg=seg, kscale=ks.to(d_), splitk=splitk)
+        ref = base.double().reshape(d0, pac, row).clone()
+        ref[:, :, :Dd] += torch.einsum('ro,rsj->osj', (dy * ks[:, None]).double(), xd.double())
+        close(dW, ref.reshape(d0, K0), what='weight gradient into the data columns (splitk %d)' % splitk)
+        assert torch.equal(dW.view(d0, pac, row)[:, :, Dd:].cpu(), base.view(d0, pac, row)[:, :, Dd:])
+    with pytest.raises(RuntimeError, match='seg_pad'):
+        ops.gemm(Xc, W1d, out, trans_b=True, beta=1.0, seg_b=1, seg=(Dd, P + 4, row))
+    with pytest.raises(RuntimeError, match='runs past'):       # a padded segment longer than what is left of W1's row
+        ops.gemm(Xc[:, :P].contiguous(), torch.zeros(d0, P - 1, device=d_), out, trans_b=True, beta=1.0, seg_b=1, seg=(Dd, P, row))
+
+
 def test_gemm_rejects_bad_arguments(ops):
     A = torch.zeros(4, 4, device=dev())
     with pytest.raises(ValueError):
@@ -511,16 +559,12 @@ def test_gather_gemm_equals_dense_linear_over_hot_columns(ops, B, C, F, Kd):
         out = torch.full((B, F), float('nan'), device=d_)
         ops.gemm_gather(inp[:, :Kd], Wd[:, :Kd], out, WcT, sel, bias=b.to(d_), epi=epi)
         close(out, torch.relu(ref) if epi else ref, what='gather gemm epi %d' % epi)
-    # every block tile (the 64x64 one prefetches the gathered rows before its K loop, the others stage them after it)
-    from dp_cgans_amd._lib import lib
-    try:
-        for tile in (64, 128, 12864, 64128):
-            lib().call('dpc_gemm_config', tile)
-            out = torch.full((B, F), float('nan'), device=d_)
-            ops.gemm_gather(inp[:, :Kd], Wd[:, :Kd], out, WcT, sel, bias=b.to(d_))
-            close(out, ref, what='gather gemm tile %d' % tile)
-    finally:
-        lib().call('dpc_gemm_config', 0)
+    # both block tiles (the 64x64 one prefetches the gathered rows before its K loop, the 128x128 one stages them
+    # after it), chosen per call: the library keeps no GEMM state
+    for tile in (64, 128):
+        out = torch.full((B, F), float('nan'), device=d_)
+        ops.gemm(inp[:, :Kd], Wd[:, :Kd], out, trans_b=True, bias=b.to(d_), gat=WcT, gidx=sel, tile=tile)
+        close(out, ref, what='gather gemm tile %d' % tile)
     # rows that are not one-/two-hot are counted
     inp[3, Kd:Kd + 3] = 1
     inp[5, Kd] = 0.5

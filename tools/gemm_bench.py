@@ -34,10 +34,8 @@ def main():
     tot_ms, tot_fl = 0.0, 0.0
     from dp_cgans_amd._lib import lib
     TILES = [0]
-    lib().cdll.dpc_gemm_streamk_config(int(os.environ.get('DPC_STREAMK', '-1')))     # -1: split-K (the default), 0: stream-K (automatic)
-    lib().cdll.dpc_gemm_prefetch(int(os.environ.get('DPC_GEMM_PF', '0')))
     if len(sys.argv) > 1 and sys.argv[1] == 'tiles':
-        TILES = [0, 64, 12864, 64128, 128]
+        TILES = [0, 64, 128]
     for tag, M, N, K, ta, tb, epi in [sh for sh in SHAPES for _ in TILES]:
         def mat(r, c):      # rows padded to 16 bytes, as the engine's buffers are
             return torch.randn(r, (c + 3) // 4 * 4, device=dev)[:, :c]
@@ -52,7 +50,7 @@ def main():
             kw = dict(epi=2, aux_in=aux)
         tile = TILES[0]
         TILES.append(TILES.pop(0))
-        lib().cdll.dpc_gemm_config(tile)
+        kw['tile'] = tile
         tag = '%s t%-5d' % (tag, tile)
         for _ in range(3):
             ops.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)

@@ -26,18 +26,17 @@ for tag, M, N, K, ta, tb in SHAPES:
     B = mat(N, K) if tb else mat(K, N)
     C = torch.zeros(M, N, device=dev)
     best = {}
-    for tile in (64, 12864, 64128, 128):
-        lib().cdll.dpc_gemm_config(tile)
+    for tile in (64,):
         line = []
         for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
             if sp > 1 and K // sp < 128:
                 continue
             for _ in range(2):
-                ops.gemm(A, B, C, trans_a=ta, trans_b=tb, splitk=sp)
+                ops.gemm(A, B, C, trans_a=ta, trans_b=tb, splitk=sp, tile=tile)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.gemm(A, B, C, trans_a=ta, trans_b=tb, splitk=sp)
+                ops.gemm(A, B, C, trans_a=ta, trans_b=tb, splitk=sp, tile=tile)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
@@ -45,7 +44,6 @@ for tag, M, N, K, ta, tb in SHAPES:
             if tile not in best or us < best[tile][0]:
                 best[tile] = (us, sp)
         print('%-14s M=%5d N=%5d K=%5d tile %-5d  %s' % (tag, M, N, K, tile, '  '.join(line)), flush=True)
-    lib().cdll.dpc_gemm_config(0)
     for _ in range(2):
         ops.gemm(A, B, C, trans_a=ta, trans_b=tb)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,12 +25,12 @@ def per_kernel(path):
 
 def main():
     F, W = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-    is_gemm = lambda k: 'gemm_f32_kernel' in k or 'gemm_streamk_kernel' in k     # one of the two per GEMM call
+    is_gemm = lambda k: 'gemm_f32_kernel' in k
     gf = [v for k, vs in F.items() if is_gemm(k) for v in vs]
     gw = [v for k, vs in W.items() if is_gemm(k) for v in vs]
     cal = [v for k, vs in F.items() if 'activate_fwd_kernel' in k for v in vs]
     out = {
-        'kernel': 'gemm_f32_kernel + gemm_streamk_kernel', 'launches': len(gf),
+        'kernel': 'gemm_f32_kernel', 'launches': len(gf),
         'fetch_size_kib_avg': sum(gf) / len(gf), 'write_size_kib_avg': sum(gw) / len(gw),
         'fetch_correction': 2.0,
         'traffic_bytes_per_launch': (2.0 * sum(gf) / len(gf) + sum(gw) / len(gw)) * 1024.0,
