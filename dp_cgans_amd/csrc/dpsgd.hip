@@ -178,7 +178,25 @@ struct GramAllArgs {
   //   fake_i . v0_i = f_i * (u_i . zpre_i),  real_i . v0_i = f_i * (u_i . zpre_{n+i}),  v0_i . v0_i = f_i^2 q_i
   const float* zpre; int64_t ldz; const float* gp_f; const double* gp_q; float* fc_out;
   float* zero;     // == zpre when its rows are to be cleared once read (the next step's split-K product adds into them)
+  // cond columns kept out of act[0] (sel_a != NULL): act[0] rows hold the DATA columns of the pac-row input
+  // only (zero padded), and the inner products of the two-hot cond parts are counted from the hot ids:
+  // sel_a / sel_b int32 [n*pac][2] ids of the fake / real sub-rows (negative = none).
+  const int32_t* sel_a; const int32_t* sel_b; int pac;
 };
+
+// |A|, |B| and |A n B| summed over the pac sub-rows of example i, A / B = the sets of hot ids of a sub-row
+__device__ __forceinline__ void cond_gram_counts(const GramAllArgs& a, int64_t i, double& aa, double& ab, double& bb) {
+  int naa = 0, nab = 0, nbb = 0;
+  for (int s = 0; s < a.pac; ++s) {
+    const int64_t q = (i * a.pac + s) * 2;
+    const int a0 = a.sel_a[q], a1 = a.sel_a[q + 1], b0 = a.sel_b[q], b1 = a.sel_b[q + 1];
+    const bool va0 = a0 >= 0, va1 = a1 >= 0 && a1 != a0, vb0 = b0 >= 0, vb1 = b1 >= 0 && b1 != b0;
+    naa += (int)va0 + (int)va1;
+    nbb += (int)vb0 + (int)vb1;
+    nab += (int)(va0 && ((vb0 && a0 == b0) || (vb1 && a0 == b1))) + (int)(va1 && ((vb0 && a1 == b0) || (vb1 && a1 == b1)));
+  }
+  aa = naa; ab = nab; bb = nbb;
+}
 
 __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) {
   __shared__ double red[4][12];
@@ -219,6 +237,11 @@ __global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) 
 #pragma unroll
         for (int q = 0; q < 12; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
         if (implicit) {
+          if (a.sel_a) {
+            double aa, ab, bb;
+            cond_gram_counts(a, i, aa, ab, bb);
+            t[6] += aa; t[7] += ab; t[9] += bb;
+          }
           const double f = (double)a.gp_f[i];
           t[8] *= f;
           t[10] *= f;
@@ -250,7 +273,8 @@ static int persample_clip_all_impl(int nlayers, const float* const* delta, const
                                    const float* const* act, const int64_t* lda, const int* K, int64_t n, float clip,
                                    float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
                                    float* norm_out, float* zpre, int64_t ldz, const float* gp_f,
-                                   const double* gp_q, float* fc_out, int clear_zpre, void* stream) {
+                                   const double* gp_q, float* fc_out, int clear_zpre, const int32_t* sel_a,
+                                   const int32_t* sel_b, int pac, void* stream) {
   DPC_CHECK_ARG(nlayers >= 1 && nlayers <= DPC_MAX_LAYERS, "persample_clip_all: 1..8 layers");
   DPC_CHECK_ARG(delta && ldd && d && act && lda && K && norm2 && rowc && n > 0, "persample_clip_all: null pointer");
   DPC_CHECK_ARG(!fc_out || gp_f, "persample_clip_all: fc_out needs gp_f");
@@ -266,6 +290,7 @@ static int persample_clip_all_impl(int nlayers, const float* const* delta, const
   a.nlayers = nlayers; a.n = n; a.clip = clip; a.gscale = gscale; a.norm2 = norm2; a.rowc = rowc; a.roww = roww;
   a.rowc_w = rowc_w; a.norm_out = norm_out;
   a.zpre = zpre; a.ldz = ldz; a.gp_f = gp_f; a.gp_q = gp_q; a.fc_out = fc_out; a.zero = clear_zpre ? zpre : nullptr;
+  a.sel_a = sel_a; a.sel_b = sel_b; a.pac = pac;
   hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(256), 0,
                      (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
@@ -277,7 +302,7 @@ extern "C" int dpc_persample_clip_all(int nlayers, const float* const* delta, co
                                       float gscale, double* norm2, float* rowc, const float* roww, float* rowc_w,
                                       float* norm_out, void* stream) {
   return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
-                                 norm_out, nullptr, 0, nullptr, nullptr, nullptr, 0, stream);
+                                 norm_out, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, stream);
 }
 
 // The same with the penalty row of layer 0 left implicit (see GramAllArgs): act[0] is [2n, K[0]] (fake and
@@ -289,11 +314,12 @@ extern "C" int dpc_persample_clip_all_gram(int nlayers, const float* const* delt
                                            float clip, float gscale, double* norm2, float* rowc, const float* roww,
                                            float* rowc_w, float* norm_out, float* zpre, int64_t ldz,
                                            const float* gp_f, const double* gp_q, float* fc_out, int clear_zpre,
-                                           void* stream) {
+                                           const int32_t* sel_a, const int32_t* sel_b, int pac, void* stream) {
   DPC_CHECK_ARG(zpre && gp_f && gp_q, "persample_clip_all_gram: null pointer");
+  DPC_CHECK_ARG(!sel_a || (sel_b && pac >= 1), "persample_clip_all_gram: cond ids need both tables and pac");
   DPC_CHECK_ARG(nlayers >= 1 && d && ldz >= d[0], "persample_clip_all_gram: ldz < d[0]");
   return persample_clip_all_impl(nlayers, delta, ldd, d, act, lda, K, n, clip, gscale, norm2, rowc, roww, rowc_w,
-                                 norm_out, zpre, ldz, gp_f, gp_q, fc_out, clear_zpre, stream);
+                                 norm_out, zpre, ldz, gp_f, gp_q, fc_out, clear_zpre, sel_a, sel_b, pac, stream);
 }
 
 // c_i = min(1, clip / (gscale * sqrt(norm2[i]))); rowc[p*n + i] = c_i for the three rows of example i

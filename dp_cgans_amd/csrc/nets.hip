@@ -614,7 +614,44 @@ struct FirstActArgs {
   float* H; int64_t ldh; float* S; int64_t lds; float* alpha_out;
   int stacked;      // 1: zpre [2n, d] -> 3n stacked rows (above); 0: zpre [n, d] -> n rows, no interpolates
   float* zero;      // == zpre (mutable) when the products are to be cleared once read (see the entry point)
+  // cond columns taken off the matrix cores (gat != NULL): zpre holds the products over the DATA columns of
+  // the pac-row input only, and the two-hot cond vector of each of a row's pac sub-rows adds the matching
+  // rows of gat = W1[:, cond columns]^T [pac*C][ldg]: sub-row s with hot id c -> row s*C + c.  sel_a: ids of
+  // the first block of rows (fake), sel_b: of the second (real; stacked only), int32 [n*pac][2], negative = none.
+  const float* gat; int64_t ldg; const int32_t* sel_a; const int32_t* sel_b; int pac; int C;
+  float* wb;        // == zpre when the gathered share is to be added to the stored products (they are kept for
+                    // the per-example Gram kernel, which needs x W1^T over ALL columns)
 };
+
+// sum over a row's pac sub-rows of the (up to two) hot rows of gat, 4 consecutive columns from j
+__device__ __forceinline__ float4 first_act_gather4(const FirstActArgs& a, const int32_t* __restrict__ sel, int64_t r, int j) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int32_t* ids = sel + r * a.pac * 2;
+  for (int s = 0; s < a.pac; ++s) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int id = ids[2 * s + h];
+      if (id >= 0) {
+        const float4 w = *reinterpret_cast<const float4*>(a.gat + ((int64_t)s * a.C + id) * a.ldg + j);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float first_act_gather1(const FirstActArgs& a, const int32_t* __restrict__ sel, int64_t r, int j) {
+  float v = 0.f;
+  const int32_t* ids = sel + r * a.pac * 2;
+  for (int s = 0; s < a.pac; ++s) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int id = ids[2 * s + h];
+      if (id >= 0) v += a.gat[((int64_t)s * a.C + id) * a.ldg + j];
+    }
+  }
+  return v;
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
@@ -641,6 +678,16 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
       zf[0] = f4.x; zf[1] = f4.y; zf[2] = f4.z; zf[3] = f4.w;
       zr[0] = r4.x; zr[1] = r4.y; zr[2] = r4.z; zr[3] = r4.w;
       b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+      if (a.gat) {
+        const float4 ga = first_act_gather4(a, a.sel_a, r, j);
+        zf[0] += ga.x; zf[1] += ga.y; zf[2] += ga.z; zf[3] += ga.w;
+        if (a.wb) *reinterpret_cast<float4*>(a.wb + r * a.ldz + j) = make_float4(zf[0], zf[1], zf[2], zf[3]);
+        if (a.stacked) {
+          const float4 gb = first_act_gather4(a, a.sel_b, r, j);
+          zr[0] += gb.x; zr[1] += gb.y; zr[2] += gb.z; zr[3] += gb.w;
+          if (a.wb) *reinterpret_cast<float4*>(a.wb + (a.n + r) * a.ldz + j) = make_float4(zr[0], zr[1], zr[2], zr[3]);
+        }
+      }
     } else {
       zf[0] = a.zpre[r * a.ldz + j];
       zr[0] = a.stacked ? a.zpre[(a.n + r) * a.ldz + j] : 0.f;
@@ -648,6 +695,14 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
       if (a.zero) {
         a.zero[r * a.ldz + j] = 0.f;
         if (a.stacked) a.zero[(a.n + r) * a.ldz + j] = 0.f;
+      }
+      if (a.gat) {
+        zf[0] += first_act_gather1(a, a.sel_a, r, j);
+        if (a.wb) a.wb[r * a.ldz + j] = zf[0];
+        if (a.stacked) {
+          zr[0] += first_act_gather1(a, a.sel_b, r, j);
+          if (a.wb) a.wb[(a.n + r) * a.ldz + j] = zr[0];
+        }
       }
     }
     const int np = a.stacked ? 3 : 1;
@@ -688,8 +743,10 @@ extern "C" int dpc_disc_first_layer_act(float* zpre, int64_t ldz, const float* b
                                         const float* alpha_inj, const uint8_t* keep, int64_t ld_keep,
                                         const uint64_t* rng, uint32_t site_alpha, uint32_t site_keep, float leak,
                                         float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, int stacked,
-                                        int clear_zpre, void* stream) {
+                                        int clear_zpre, const float* gat, int64_t ldg, const int32_t* sel_a,
+                                        const int32_t* sel_b, int pac, int C, void* stream) {
   DPC_CHECK_ARG(zpre && bias && H && S && n > 0 && d > 0, "disc_first_layer_act: bad argument");
+  DPC_CHECK_ARG(!gat || (sel_a && (sel_b || !stacked) && pac >= 1 && C >= 1 && ldg >= d), "disc_first_layer_act: cond gather needs ids, pac, C and ldg >= d");
   DPC_CHECK_ARG(ldz >= d && ldh >= d && lds >= d, "disc_first_layer_act: leading dimension < d");
   DPC_CHECK_ARG(((alpha_inj || !stacked) && keep) || rng, "disc_first_layer_act: no random source");
   DPC_CHECK_ARG(!keep || ld_keep >= d, "disc_first_layer_act: ld_keep < d");
@@ -697,8 +754,11 @@ extern "C" int dpc_disc_first_layer_act(float* zpre, int64_t ldz, const float* b
   a.zpre = zpre; a.ldz = ldz; a.bias = bias; a.n = n; a.d = d; a.alpha_inj = alpha_inj; a.keep = keep; a.ld_keep = ld_keep;
   a.rng = rng; a.site_alpha = site_alpha; a.site_keep = site_keep; a.leak = leak; a.H = H; a.ldh = ldh; a.S = S; a.lds = lds;
   a.alpha_out = alpha_out; a.stacked = stacked ? 1 : 0; a.zero = clear_zpre ? zpre : nullptr;
+  a.gat = gat; a.ldg = ldg; a.sel_a = sel_a; a.sel_b = sel_b; a.pac = pac; a.C = C;
+  a.wb = (gat && !clear_zpre) ? zpre : nullptr;
   const bool vec = (d % 4 == 0) && (ldz % 4 == 0) && (ldh % 4 == 0) && (lds % 4 == 0) &&
-                   ((((uintptr_t)zpre | (uintptr_t)bias | (uintptr_t)H | (uintptr_t)S) & 15) == 0);
+                   ((((uintptr_t)zpre | (uintptr_t)bias | (uintptr_t)H | (uintptr_t)S) & 15) == 0) &&
+                   (!gat || ((ldg % 4 == 0) && (((uintptr_t)gat & 15) == 0)));
   if (vec)
     hipLaunchKernelGGL(disc_first_act_kernel<true>, dim3(dpc_grid(n * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, a);
   else

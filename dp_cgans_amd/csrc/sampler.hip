@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict
                                                          const int64_t* __restrict__ row_id, int64_t B, int Dd,
                                                          float* __restrict__ out, int64_t ldo,
                                                          const int32_t* __restrict__ sel,
-                                                         const int64_t* __restrict__ perm, int C) {
+                                                         const int64_t* __restrict__ perm, int C,
+                                                         int32_t* __restrict__ sel_out) {
   const int lane = threadIdx.x & 63;
   int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -358,16 +359,22 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict
     int64_t s = perm ? perm[b] : b;
     int ca = sel[2 * s], cb = sel[2 * s + 1];
     for (int c = lane; c < C; c += 64) dst[Dd + c] = (c == ca || c == cb) ? 1.f : 0.f;
+    if (sel_out && lane == 0) {              // the cond vector that travels with the row, as its two hot ids
+      sel_out[2 * b] = ca;
+      sel_out[2 * b + 1] = cb;
+    }
   }
 }
 
 extern "C" int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd, float* out,
-                              int64_t ldo, const int32_t* sel, const int64_t* perm, int C, void* stream) {
+                              int64_t ldo, const int32_t* sel, const int64_t* perm, int C, int32_t* sel_out,
+                              void* stream) {
   DPC_CHECK_ARG(table && row_id && out, "row_gather: null pointer");
+  DPC_CHECK_ARG(!sel_out || sel, "row_gather: sel_out needs sel");
   DPC_CHECK_ARG(B >= 0 && Dd > 0 && ld >= Dd && ldo >= Dd + (sel ? C : 0), "row_gather: bad shape");
   if (B == 0) return DPC_OK;
   hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)dpc_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, table, ld,
-                     row_id, B, Dd, out, ldo, sel, perm, C);
+                     row_id, B, Dd, out, ldo, sel, perm, C, sel_out);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

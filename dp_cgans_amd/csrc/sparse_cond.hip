@@ -56,15 +56,16 @@ extern "C" int dpc_cond_to_sel(const float* cond, int64_t ld, int64_t B, int C, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Up to 8 transposes in one launch: dst_k[c][r] = src_k[r][c], r < rows_k, c < cols_k (32 x 32 LDS
+// Up to 16 transposes in one launch: dst_k[c][r] = src_k[r][c], r < rows_k, c < cols_k (32 x 32 LDS
 // tiles, both sides coalesced).  Keeps W[:, cond columns]^T of every generator layer current after
 // an optimiser step, and writes the scattered cond-column gradients back into dW's layout.
 // ---------------------------------------------------------------------------------------------
-#define DPC_MAX_SLICES 8
+#define DPC_MAX_SLICES 16
 struct TransArgs {
   const float* src[DPC_MAX_SLICES]; int64_t ld_src[DPC_MAX_SLICES];
   float* dst[DPC_MAX_SLICES]; int64_t ld_dst[DPC_MAX_SLICES];
   int rows[DPC_MAX_SLICES], cols[DPC_MAX_SLICES];
+  int accumulate;      // dst += src^T instead of dst = src^T
 };
 
 __global__ __launch_bounds__(256) void transpose_slices_kernel(TransArgs a) {
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(256) void transpose_slices_kernel(TransArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = c0 + ty + 8 * i, r = r0 + tx;
-      if (c < cols && r < rows) a.dst[k][(int64_t)c * a.ld_dst[k] + r] = tile[tx][ty + 8 * i];
+      if (c < cols && r < rows) {
+        float* dp = a.dst[k] + (int64_t)c * a.ld_dst[k] + r;
+        *dp = a.accumulate ? *dp + tile[tx][ty + 8 * i] : tile[tx][ty + 8 * i];
+      }
     }
     __syncthreads();
   }
@@ -92,10 +96,12 @@ __global__ __launch_bounds__(256) void transpose_slices_kernel(TransArgs a) {
 
 // src / dst / ld_src / ld_dst / rows / cols: HOST arrays of nslices (<= 8) entries.
 extern "C" int dpc_transpose_slices(int nslices, const float* const* src, const int64_t* ld_src, const int* rows,
-                                    const int* cols, float* const* dst, const int64_t* ld_dst, void* stream) {
-  DPC_CHECK_ARG(nslices >= 1 && nslices <= DPC_MAX_SLICES, "transpose_slices: 1..8 slices");
+                                    const int* cols, float* const* dst, const int64_t* ld_dst, int accumulate,
+                                    void* stream) {
+  DPC_CHECK_ARG(nslices >= 1 && nslices <= DPC_MAX_SLICES, "transpose_slices: 1..16 slices");
   DPC_CHECK_ARG(src && ld_src && rows && cols && dst && ld_dst, "transpose_slices: null pointer");
   TransArgs a;
+  a.accumulate = accumulate ? 1 : 0;
   int maxt = 1;
   for (int k = 0; k < nslices; ++k) {
     DPC_CHECK_ARG(src[k] && dst[k] && rows[k] > 0 && cols[k] > 0 && ld_src[k] >= cols[k] && ld_dst[k] >= rows[k],
@@ -112,29 +118,92 @@ extern "C" int dpc_transpose_slices(int nslices, const float* const* src, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Counting sort of the (row, hot id) pairs of sel by id: order[p] = row, sid[p] = id for p < *n_items,
-// ids ascending (rows of one id in arbitrary order).  One block; histogram, scan and cursors live in
-// LDS (C <= 15360).  It lets dpc_hot_rows_sum add the rows of one id inside a block instead of with one
-// atomic per element: the ids of a batch are Zipf-distributed, and thousands of same-address atomics
-// serialise in L2 (30 us per layer at T1M against 5 us this way).
+// Counting sort of (row, hot id) pairs by id: order[p] = row, sid[p] = id for p < *n_items, ids ascending
+// (rows of one id in arbitrary order).  It lets dpc_hot_rows_sum add the rows of one id inside a block
+// instead of with one atomic per element: the ids of a batch are Zipf-distributed, and thousands of
+// same-address atomics serialise in L2 (30 us per layer at T1M against 5 us this way).
+// Pairs come from one or two id tables sel_a / sel_b int32 [B][2] (negative = no id).  With pac > 1 the B
+// sub-rows are grouped pac to a row, as the discriminator's input is (dp_cgan.py:66-68): sub-row b of table
+// t yields row t * (B / pac) + b / pac and id (b % pac) * C + sel[b][h] - the cond column inside the pac row.
+// Multi-block without a grid-wide pass: block k owns the id range [lo, hi), reads ALL pairs (a few hundred
+// KB, L2-resident), counts those below its range in registers (their total is where its output starts)
+// and those inside in an LDS histogram, scans it and scatters its own pairs.  No global atomics, no
+// workspace, any number of ids (the one-block version stopped at 15360).
 // ---------------------------------------------------------------------------------------------
-#define DPC_SORT_MAX_C 15360          // (C + 1024) * 4 bytes of dynamic LDS <= 64 KB
-__global__ __launch_bounds__(1024) void hot_sort_kernel(const int32_t* __restrict__ sel, int64_t B, int C,
-                                                        int32_t* __restrict__ order, int32_t* __restrict__ sid,
-                                                        int32_t* __restrict__ n_items) {
-  extern __shared__ int32_t hist[];          // C bins + 1024 scan slots
-  int32_t* scan = hist + C;
-  const int t = threadIdx.x, nt = blockDim.x;
-  for (int c = t; c < C; c += nt) hist[c] = 0;
-  __syncthreads();
-  for (int64_t p = t; p < 2 * B; p += nt) {
-    const int id = sel[p];
-    if (id >= 0 && id < C) atomicAdd(&hist[id], 1);
+#define DPC_SORT_MAX_BINS 12288          // (bins + 1024) * 4 bytes of dynamic LDS <= 64 KB
+struct SortArgs {
+  const int32_t* sel[2]; int ntab; int64_t B; int pac; int C; int bins;
+  int32_t* order; int32_t* sid; int32_t* n_items;
+  float inv_pac;
+};
+
+// (row, id) of pair p, p < ntab * 2B < 2^31: 32-bit arithmetic only (a 64-bit division per pair made the
+// first version of this kernel slower than the one-block sort it replaced)
+__device__ __forceinline__ bool sort_item(const SortArgs& a, uint32_t p, int raw, int& id, int& row) {
+  if (raw < 0 || raw >= a.C) return false;
+  const uint32_t per = 2u * (uint32_t)a.B;
+  const uint32_t tab = p >= per ? 1u : 0u;
+  const uint32_t b = (p - tab * per) >> 1;
+  uint32_t grp = b;
+  if (a.pac > 1) {
+    grp = (uint32_t)((float)b * a.inv_pac);          // b / pac, corrected (b < 2^24: exact float)
+    if ((grp + 1) * (uint32_t)a.pac <= b) ++grp;
+    if (grp * (uint32_t)a.pac > b) --grp;
   }
+  id = (int)(b - grp * (uint32_t)a.pac) * a.C + raw;
+  row = (int)(tab * (uint32_t)(a.B / a.pac) + grp);
+  return true;
+}
+
+// IPT pairs per thread stay in registers between the counting and the scatter pass, loaded with
+// independent loads up front (a load -> LDS-atomic loop is a chain of L2 round trips: 16 iterations took
+// 25 us); IPT == 0: any number of pairs, read twice.
+template <int IPT>
+__global__ __launch_bounds__(1024) void hot_sort_kernel(SortArgs a) {
+  extern __shared__ int32_t hist[];          // bins + 1024 scan slots
+  __shared__ int32_t red[16];
+  int32_t* scan = hist + a.bins;
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int lo = blockIdx.x * a.bins, hi = min(lo + a.bins, a.pac * a.C);
+  const int nb = hi - lo;
+  const uint32_t nitem = (uint32_t)a.ntab * 2u * (uint32_t)a.B, per = 2u * (uint32_t)a.B;
+  int raw[IPT > 0 ? IPT : 1];
+  if (IPT > 0) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const uint32_t p = (uint32_t)t + (uint32_t)k * 1024u;
+      raw[k] = p < nitem ? (p >= per ? a.sel[1][p - per] : a.sel[0][p]) : -1;
+    }
+  }
+  for (int c = t; c < nb; c += nt) hist[c] = 0;
   __syncthreads();
-  // exclusive scan: each thread owns a contiguous run of bins
-  const int per = (C + nt - 1) / nt;
-  const int c0 = min(C, t * per), c1 = min(C, c0 + per);
+  int below = 0;
+  if (IPT > 0) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      int id, row;
+      if (!sort_item(a, (uint32_t)t + (uint32_t)k * 1024u, raw[k], id, row)) continue;
+      if (id < lo) ++below;
+      else if (id < hi) atomicAdd(&hist[id - lo], 1);
+    }
+  } else {
+    for (uint32_t p = t; p < nitem; p += nt) {
+      int id, row;
+      if (!sort_item(a, p, p >= per ? a.sel[1][p - per] : a.sel[0][p], id, row)) continue;
+      if (id < lo) ++below;
+      else if (id < hi) atomicAdd(&hist[id - lo], 1);
+    }
+  }
+  // pairs below this block's range: where its output starts
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = below;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (nt >> 6); ++w) base += red[w];
+  // exclusive scan of the histogram: each thread owns a contiguous run of bins
+  const int perb = (nb + nt - 1) / nt;
+  const int c0 = min(nb, t * perb), c1 = min(nb, c0 + perb);
   int sum = 0;
   for (int c = c0; c < c1; ++c) sum += hist[c];
   scan[t] = sum;
@@ -145,30 +214,55 @@ __global__ __launch_bounds__(1024) void hot_sort_kernel(const int32_t* __restric
     scan[t] += v;
     __syncthreads();
   }
-  int run = scan[t] - sum;
+  int run = base + scan[t] - sum;
   for (int c = c0; c < c1; ++c) {
     const int h = hist[c];
     hist[c] = run;
     run += h;
   }
-  if (t == nt - 1) n_items[0] = scan[t];
+  if (t == nt - 1 && blockIdx.x == gridDim.x - 1) a.n_items[0] = base + scan[t];
   __syncthreads();
-  for (int64_t p = t; p < 2 * B; p += nt) {
-    const int id = sel[p];
-    if (id >= 0 && id < C) {
-      const int pos = atomicAdd(&hist[id], 1);
-      order[pos] = (int32_t)(p >> 1);
-      sid[pos] = id;
+  if (IPT > 0) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      int id, row;
+      if (!sort_item(a, (uint32_t)t + (uint32_t)k * 1024u, raw[k], id, row) || id < lo || id >= hi) continue;
+      const int pos = atomicAdd(&hist[id - lo], 1);
+      a.order[pos] = row;
+      a.sid[pos] = id;
+    }
+  } else {
+    for (uint32_t p = t; p < nitem; p += nt) {
+      int id, row;
+      if (!sort_item(a, p, p >= per ? a.sel[1][p - per] : a.sel[0][p], id, row) || id < lo || id >= hi) continue;
+      const int pos = atomicAdd(&hist[id - lo], 1);
+      a.order[pos] = row;
+      a.sid[pos] = id;
     }
   }
 }
 
-extern "C" int dpc_hot_sort(const int32_t* sel, int64_t B, int C, int32_t* order, int32_t* sid, int32_t* n_items,
-                            void* stream) {
-  DPC_CHECK_ARG(sel && order && sid && n_items && B > 0 && C > 0, "hot_sort: bad argument");
-  DPC_CHECK_ARG(C <= DPC_SORT_MAX_C && 2 * B < (1ll << 31), "hot_sort: more than 15360 ids");
-  hipLaunchKernelGGL(hot_sort_kernel, dim3(1), dim3(1024), (size_t)(C + 1024) * sizeof(int32_t), (hipStream_t)stream, sel, B,
-                     C, order, sid, n_items);
+extern "C" int dpc_hot_sort(const int32_t* sel_a, const int32_t* sel_b, int64_t B, int pac, int C, int32_t* order,
+                            int32_t* sid, int32_t* n_items, void* stream) {
+  DPC_CHECK_ARG(sel_a && order && sid && n_items && B > 0 && C > 0 && pac >= 1, "hot_sort: bad argument");
+  DPC_CHECK_ARG(B % pac == 0, "hot_sort: B must be a multiple of pac");
+  DPC_CHECK_ARG(4 * B < (1ll << 31) && (int64_t)pac * C < (1ll << 30), "hot_sort: too many pairs or ids");
+  const int64_t ids = (int64_t)pac * C;
+  int64_t nblk = dpc_cdiv(ids, 64);                           // ~64 ids per block until 128 blocks are busy
+  if (nblk > 128) nblk = 128;
+  if (nblk < dpc_cdiv(ids, DPC_SORT_MAX_BINS)) nblk = dpc_cdiv(ids, DPC_SORT_MAX_BINS);
+  SortArgs a;
+  a.sel[0] = sel_a; a.sel[1] = sel_b; a.ntab = sel_b ? 2 : 1; a.B = B; a.pac = pac; a.C = C;
+  a.bins = (int)dpc_cdiv(ids, nblk);
+  nblk = dpc_cdiv(ids, a.bins);
+  a.order = order; a.sid = sid; a.n_items = n_items; a.inv_pac = 1.0f / (float)pac;
+  DPC_CHECK_ARG(B < (1 << 24), "hot_sort: at most 2^24 sub-rows");
+  const int64_t nitem = (int64_t)a.ntab * 2 * B;
+  const size_t lds = (size_t)(a.bins + 1024) * sizeof(int32_t);
+  hipStream_t st = (hipStream_t)stream;
+  if (nitem <= 1024 * 8) hipLaunchKernelGGL(hot_sort_kernel<8>, dim3((unsigned)nblk), dim3(1024), lds, st, a);
+  else if (nitem <= 1024 * 32) hipLaunchKernelGGL(hot_sort_kernel<32>, dim3((unsigned)nblk), dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL(hot_sort_kernel<0>, dim3((unsigned)nblk), dim3(1024), lds, st, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -185,9 +279,10 @@ __global__ __launch_bounds__(256) void hot_rows_sum_kernel(const float* __restri
                                                            const int32_t* __restrict__ order,
                                                            const int32_t* __restrict__ sid,
                                                            const int32_t* __restrict__ n_items, float* __restrict__ acc,
-                                                           int64_t ld_acc) {
+                                                           int64_t ld_acc, const float* __restrict__ rowscale) {
   constexpr int CH = 64;
   __shared__ int32_t row_s[CH], id_s[CH];
+  __shared__ float sc_s[CH];
   const int n = n_items[0];
   const int p0 = blockIdx.x * CH;
   if (p0 >= n) return;
@@ -195,6 +290,7 @@ __global__ __launch_bounds__(256) void hot_rows_sum_kernel(const float* __restri
   if (threadIdx.x < cnt) {
     row_s[threadIdx.x] = order[p0 + threadIdx.x];
     id_s[threadIdx.x] = sid[p0 + threadIdx.x];
+    sc_s[threadIdx.x] = rowscale ? rowscale[row_s[threadIdx.x]] : 1.f;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < F; j += blockDim.x) {
@@ -204,7 +300,7 @@ __global__ __launch_bounds__(256) void hot_rows_sum_kernel(const float* __restri
     for (; i + 8 <= cnt; i += 8) {            // 8 independent row loads in flight
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = dy[(int64_t)row_s[i + q] * ld + j];
+      for (int q = 0; q < 8; ++q) v[q] = dy[(int64_t)row_s[i + q] * ld + j] * sc_s[i + q];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int id = id_s[i + q];
@@ -223,7 +319,7 @@ __global__ __launch_bounds__(256) void hot_rows_sum_kernel(const float* __restri
         sum = 0.f;
         cur = id;
       }
-      sum += dy[(int64_t)row_s[i] * ld + j];
+      sum += dy[(int64_t)row_s[i] * ld + j] * sc_s[i];
     }
     atomicAdd(acc + (int64_t)cur * ld_acc + j, sum);
   }
@@ -231,11 +327,12 @@ __global__ __launch_bounds__(256) void hot_rows_sum_kernel(const float* __restri
 
 // max_items: the capacity of order / sid (2B); the grid is sized for it, blocks beyond *n_items exit.
 extern "C" int dpc_hot_rows_sum(const float* dy, int64_t ld, int F, const int32_t* order, const int32_t* sid,
-                                const int32_t* n_items, int64_t max_items, float* acc, int64_t ld_acc, void* stream) {
+                                const int32_t* n_items, int64_t max_items, float* acc, int64_t ld_acc,
+                                const float* rowscale, void* stream) {
   DPC_CHECK_ARG(dy && order && sid && n_items && acc && F > 0 && ld >= F && ld_acc >= F && max_items > 0,
                 "hot_rows_sum: bad argument");
   hipLaunchKernelGGL(hot_rows_sum_kernel, dim3((unsigned)dpc_cdiv(max_items, 64)), dim3(256), 0, (hipStream_t)stream, dy, ld,
-                     F, order, sid, n_items, acc, ld_acc);
+                     F, order, sid, n_items, acc, ld_acc, rowscale);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

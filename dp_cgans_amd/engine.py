@@ -19,6 +19,12 @@ Memory layout (all fp32, row-major, resident in HBM for the whole fit):
   Zp [2n, d_0], G1 [d_0, d_0]     Gram-form penalty (gp_gram): first-layer plain products x W1^T of the fake
                                   and real rows, and W1 W1^T; the interpolates and the K0-wide penalty
                                   gradient are then never formed (third block of Xd unused)
+  sparse_d (Gram-form penalty + two-hot cond vector): the discriminator input keeps only its DATA columns,
+                                  Xd [2B, P] = [2n, pac*P] (P = Dd rounded up to 32, zero padded); the cond
+                                  columns of every pac sub-row travel as two hot ids (GenContext.sel, sel_real)
+                                  and their share of the first layer is row gathers of W1cT = W1[:, cond
+                                  columns]^T [pac*C, d_0] (forward) and sorted row sums (weight gradient);
+                                  W1 itself stays in the reference's layout, addressed through segment maps
 """
 import contextlib
 import math
@@ -127,7 +133,7 @@ class GenContext(object):
         ldd = (eng.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
         self.fake = torch.zeros(B, ldd, **f32)[:, :eng.Dd]
         self.X = X
-        self.X3 = X.view(eng.n, eng.K0)
+        self.X3 = X.view(eng.n, eng.K0x)
         self.cond = torch.zeros(B, max(eng.C, 1), **f32)
         self.mask = torch.zeros(B, max(eng.nd, 1), device=d, dtype=torch.int32)
         self.pair_id = torch.zeros(B, device=d, dtype=torch.int64)
@@ -184,8 +190,6 @@ class StepEngine(object):
         if weight_clip is None:
             weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
         self.weight_clip = float(weight_clip)
-        # bit-reproducible steps (no split-K atomics, no scatter atomics): read once from the process default
-        self.deterministic = bool(ops.DETERMINISTIC) if deterministic is None else bool(deterministic)
         self._ar_hook = None
         self._early_hook = None
         self._inline = False
@@ -201,6 +205,8 @@ class StepEngine(object):
         self.start = [sum(self.gdim[l:]) for l in range(L)] + [0]      # start[l] = first input column of layer l
         self.row = self.Dd + self.C
         self.K0 = pac * self.row
+        # bit-reproducible steps (no split-K atomics, no scatter atomics): read once from the process default
+        self.deterministic = bool(ops.DETERMINISTIC) if deterministic is None else bool(deterministic)
         # ---- parameters ------------------------------------------------------------------------
         gs = []
         for l in range(L):
@@ -250,14 +256,29 @@ class StepEngine(object):
         self.dZ = [torch.zeros(B, w, **f32) for w in self.gdim]
         ldd = (self.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
         self.dfake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
-        self.Xd = torch.zeros(3 * B, self.row, **f32)
-        self.Xd3 = self.Xd.view(3 * n, self.K0)
-        self.Xg = torch.zeros(B, self.row, **f32)           # discriminator input of the generator update
+        # Gradient penalty through the first layer's Gram matrix W1 W1^T (see _d_back): on by default
+        # when the batch of pac groups is at least half as tall as the first hidden layer is wide
+        # (the d0 x d0 x K0 Gram product then costs less than the three n x d0 x K0 products it replaces)
+        if gp_gram is None:
+            gp_gram = StepEngine.GP_GRAM
+        self.gp_gram = bool(gp_gram) if gp_gram is not None else (2 * n >= self.ddim[0])
+        # The discriminator's input is cat([data, cond]) per sub-row (dp_cgan.py:622-623) and cond is two-hot:
+        # with the Gram-form penalty no K0-wide operand other than the input itself is left, so the cond
+        # columns (45 % of K0 at T1M) leave the matrix cores here too.  Needs the padded data segment to fit
+        # the stored one (P <= Dd + C) and the atomics of the sorted row sums (not in reproducible mode).
+        self.P = (self.Dd + 31) // 32 * 32
+        self.sparse_d = bool(self.sparse_cond and self.gp_gram and self.P <= self.row and not self.deterministic)
+        self.seg = (self.Dd, self.P, self.row)              # segment map of W1's data columns (ops.gemm_desc)
+        xrow = self.P if self.sparse_d else self.row
+        self.K0x = pac * xrow                               # length of a stored discriminator-input row
+        self.Xd = torch.zeros((2 if self.sparse_d else 3) * B, xrow, **f32)
+        self.Xd3 = self.Xd.view(-1, self.K0x)
+        self.Xg = torch.zeros(B, xrow, **f32)               # discriminator input of the generator update
         self.cd = GenContext(self, self.Xd[0:B])            # forward of the discriminator update
         self.cg = GenContext(self, self.Xg)                 # forward of the generator update (its backward reads it)
         self._last = self.cd
         self.bn_scratch = [torch.zeros(2, w, **f32) for w in self.gdim]
-        self.dX = torch.zeros(B, self.row, **f32)
+        self.dX = torch.zeros(B, xrow, **f32)
         self.H = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
         self.S = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
         self.Dl = [torch.zeros(3 * n, w, **f32) for w in self.ddim]
@@ -303,13 +324,15 @@ class StepEngine(object):
         # both backward passes (penalty, loss_d) fire every hook except the last bias's, which only
         # loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
         self.hook_fires = torch.tensor([2.0] * (len(self.disc.keys) - 1) + [1.0], **f32)
-        # Gradient penalty through the first layer's Gram matrix W1 W1^T (see _d_back): on by default
-        # when the batch of pac groups is at least half as tall as the first hidden layer is wide
-        # (the d0 x d0 x K0 Gram product then costs less than the three n x d0 x K0 products it replaces)
-        if gp_gram is None:
-            gp_gram = StepEngine.GP_GRAM
-        self.gp_gram = bool(gp_gram) if gp_gram is not None else (2 * n >= self.ddim[0])
         d0 = self.ddim[0]
+        if self.sparse_d:
+            ldw = (d0 + 3) // 4 * 4
+            self.W1cT = torch.zeros(pac * self.C, ldw, **f32)[:, :d0]       # W1[:, cond columns]^T, sub-row major
+            self.dW1cT = torch.zeros(pac * self.C, ldw, **f32)[:, :d0]      # its gradient (sorted row sums)
+            self.sel_real = torch.full((B, 2), -1, device=d, dtype=torch.int32)   # hot ids that travel with the real rows
+            self.order_d = torch.zeros(4 * B, device=d, dtype=torch.int32)  # (row, id) pairs of both blocks sorted by id
+            self.sid_d = torch.zeros(4 * B, device=d, dtype=torch.int32)
+            self.n_items_d = torch.zeros(1, device=d, dtype=torch.int32)
         self.Zp = torch.zeros(2 * n, d0, **f32)        # first layer's plain products of the fake and real rows
         self.G1 = torch.zeros(d0, d0, **f32)           # W1 W1^T
         self.Tq = torch.zeros(n, d0, **f32)            # u G1
@@ -447,17 +470,19 @@ class StepEngine(object):
                                     site=ops.SITE_ROWPICK + self._so)
                     ops.row_gather(self.sampler.table, self.row_id, real, Dd)
             return
-        fake_c = c.X[:, Dd:]
+        fake_c = None if self.sparse_d else c.X[:, Dd:]     # (sparse_d: the cond columns travel as c.sel)
         if 'cond' in inj:
             c.cond.copy_(inj['cond'])
             c.mask.copy_(inj['mask'])
             cv.copy_(c.cond)
-            fake_c.copy_(c.cond)
+            if fake_c is not None:
+                fake_c.copy_(c.cond)
             if self.sparse_cond:
                 ops.cond_to_sel(c.cond, c.sel)
         else:
             s = self.sampler
-            ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv, fake_c], c.mask, c.pair_id,
+            ops.condvec_pair_sample(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv] + ([] if fake_c is None else [fake_c]),
+                                    c.mask, c.pair_id,
                                     c.val_idx, c.sel, c.gcount, pairs_inj=inj.get('pairs'),
                                     r_inj=inj.get('r'), rng=self.rng, site=ops.SITE_CONDVEC + self._so)
         self._join()
@@ -467,7 +492,11 @@ class StepEngine(object):
         with self._fork(0):      # beside the generator forward; joined before the interpolation
             if 'real' in inj:
                 real[:, :Dd].copy_(inj['real'])
-                real[:, Dd:].copy_(inj['real_cond'] if 'real_cond' in inj else c.cond[inj['perm']])
+                real_cond = inj['real_cond'] if 'real_cond' in inj else c.cond[inj['perm']]
+                if self.sparse_d:
+                    ops.cond_to_sel(real_cond.contiguous(), self.sel_real)
+                else:
+                    real[:, Dd:].copy_(real_cond)
             else:
                 s = self.sampler
                 if 'perm' in inj:
@@ -476,7 +505,14 @@ class StepEngine(object):
                     ops.random_perm(self.rng, self.perm, self.keys_ws, site=ops.SITE_PERM + self._so)
                 ops.row_select(s.bitmaps, c.sel, c.gcount, self.row_id, perm=self.perm, k_inj=inj.get('k'),
                                rng=self.rng, cntblk=s.cntblk, site=ops.SITE_ROWPICK + self._so)
-                ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=C)
+                if self.sparse_d:
+                    ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=0, sel_out=self.sel_real)
+                else:
+                    ops.row_gather(s.table, self.row_id, real, Dd, sel=c.sel, perm=self.perm, C=C)
+            if self.sparse_d and need_real != 'rows':
+                # (row, cond id) pairs of the fake and real blocks sorted by id: the cond columns of the first
+                # layer's weight gradient are row sums in that order (_d_back)
+                ops.hot_sort(c.sel, self.C, self.order_d, self.sid_d, self.n_items_d, sel_b=self.sel_real, pac=self.pac)
             if self.gp_gram:
                 # W1 W1^T of the Gram-form penalty (see _d_back): issued here, beside the generator forward's
                 # chain of small kernels, rather than beside the discriminator's first-layer product
@@ -642,23 +678,48 @@ class StepEngine(object):
                                    site=ops.SITE_GUMBEL + self._so)      # computed and dropped, as the reference does
             c.X.copy_(c.fake)
 
-    def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None, X3=None):
+    def _w1ct(self):
+        """W1cT = W1[:, cond columns]^T, sub-row major [pac*C, d0]: refreshed after every discriminator Adam step
+        (_disc_update) and here when the parameters were loaded from outside."""
+        if self.disc.loaded:
+            self._refresh_w1ct()
+        return self.W1cT
+
+    def _refresh_w1ct(self):
+        W1, C, Dd = self.disc.P('seq.0.weight'), self.C, self.Dd
+        ops.transpose_slices([(W1[:, s * self.row + Dd:(s + 1) * self.row], self.W1cT[s * C:(s + 1) * C])
+                              for s in range(self.pac)])
+        self.disc.loaded = False
+
+    def _disc_first(self, x, zp, rows, H, S, keep, sel, **act):
+        """First hidden layer of `rows` input rows x [rows, K0x] -> H, S: the K0-long product goes split-K into
+        the all-zero zp (no memset node: the pass below, or the per-example Gram kernel, clears it again), then
+        bias + LeakyReLU + Dropout - and, with the cond columns off the matrix cores (sparse_d), the gather of
+        W1's hot cond columns - in one pass."""
+        d = self.disc
+        W1 = d.P('seq.0.weight')
+        if self.sparse_d:
+            self._mm(x, W1, zp, trans_b=True, beta=1.0, seg_b=1, seg=self.seg)
+            act.update(gat=self._w1ct(), pac=self.pac, C=self.C)
+            act.update(sel if isinstance(sel, dict) else dict(sel_a=sel))
+        else:
+            self._mm(x, W1, zp, trans_b=True, beta=1.0)
+        ops.disc_first_layer_act(zp, d.P('seq.0.bias'), rows, H, S, keep=keep, rng=self.rng,
+                                 site_keep=ops.SITE_DROP0 + self._so, leak=LEAK, **act)
+
+    def _disc_forward(self, rows, inj, row0=0, y=None, rowscale=None, X3=None, sel=None):
         """Discriminator forward over rows [row0, row0+rows) of the stacked input (or of ``X3``, whose
-        results then land in rows [row0, row0+rows) of the layer buffers); with ``rowscale`` the head
-        kernel also seeds the backward chain: Dl[M-1] = rowscale * w_last * S[M-1]."""
+        results then land in rows [row0, row0+rows) of the layer buffers; ``sel``: the hot cond ids of those
+        rows' sub-rows, sparse_d); with ``rowscale`` the head kernel also seeds the backward chain:
+        Dl[M-1] = rowscale * w_last * S[M-1]."""
         d, M = self.disc, self.M
         rs = slice(row0, row0 + rows)
         x = self.Xd3[rs] if X3 is None else X3
         keeps = inj.get('keep')
         first = 0
-        if X3 is not None and rows <= 2 * self.n:
-            # K0-long first product into the all-zero Zp (see _disc_forward_stacked: no memset node), then
-            # bias + LeakyReLU + Dropout in the pass that clears Zp again
-            zp = self.Zp[0:rows]
-            self._mm(x, d.P('seq.0.weight'), zp, trans_b=True, beta=1.0)
-            ops.disc_first_layer_act(zp, d.P('seq.0.bias'), rows, self.H[0][rs], self.S[0][rs],
-                                     keep=keeps[0] if keeps else None, rng=self.rng, site_keep=ops.SITE_DROP0 + self._so,
-                                     leak=LEAK, stacked=False, clear=True)
+        if (X3 is not None or self.sparse_d) and rows <= 2 * self.n:
+            self._disc_first(x, self.Zp[0:rows], rows, self.H[0][rs], self.S[0][rs], keeps[0] if keeps else None, sel,
+                             stacked=False, clear=True)
             x = self.H[0][rs]
             first = 1
         for i in range(first, M):
@@ -682,11 +743,10 @@ class StepEngine(object):
         # Zp is all zero here (allocated so; its last reader - the activation pass, or the per-example Gram
         # kernel in DP-SGD mode - clears what it reads): the K0-long product
         # runs split-K with its atomics adding straight into it, no memset node in front
-        self._mm(self.Xd3[0:2 * n], d.P('seq.0.weight'), self.Zp, trans_b=True, beta=1.0)
         keeps = inj.get('keep')
-        ops.disc_first_layer_act(self.Zp, d.P('seq.0.bias'), n, self.H[0], self.S[0], alpha_inj=inj.get('alpha'),
-                                 keep=keeps[0] if keeps else None, rng=self.rng, site_alpha=ops.SITE_ALPHA + self._so,
-                                 site_keep=ops.SITE_DROP0 + self._so, leak=LEAK, clear=self.dp_mode != 'dpsgd')
+        self._disc_first(self.Xd3[0:2 * n], self.Zp, n, self.H[0], self.S[0], keeps[0] if keeps else None,
+                         dict(sel_a=self.cd.sel, sel_b=self.sel_real) if self.sparse_d else None,
+                         alpha_inj=inj.get('alpha'), site_alpha=ops.SITE_ALPHA + self._so, clear=self.dp_mode != 'dpsgd')
         x = self.H[0]
         for i in range(1, M):
             self._mm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
@@ -709,9 +769,9 @@ class StepEngine(object):
         while need > 0:
             self._so = 0
             self._last = self.cd
-            self._draw_inputs(inj, need_real=True, c=self.cd)
+            self._draw_inputs(inj, need_real='rows', c=self.cd)
             self._join()
-            self._disc_forward(self.n, inj, row0=self.n, y=self.y_x)
+            self._disc_forward(self.n, inj, row0=self.n, y=self.y_x, sel=self.sel_real if self.sparse_d else None)
             ops.state_advance(self.rng)
             out.append(self.y_x[:min(need, self.n)].detach().cpu())
             need -= self.n
@@ -846,7 +906,9 @@ class StepEngine(object):
             if gram:
                 ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
                                        roww=self.rowscale_d, rowc_w=self.rowc_w, norm_out=self.norms, zpre=self.Zp,
-                                       gp_f=self.gp_f, gp_q=self.gp_q, fc_out=self.gp_fc, clear_zpre=True)
+                                       gp_f=self.gp_f, gp_q=self.gp_q, fc_out=self.gp_fc, clear_zpre=True,
+                                       sel_a=self.cd.sel if self.sparse_d else None,
+                                       sel_b=self.sel_real if self.sparse_d else None, pac=self.pac)
                 pen_scale = self.gp_fc
             else:
                 ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
@@ -868,12 +930,25 @@ class StepEngine(object):
             u = self.Dl[0][gp_rows]
             self._mm(u, u, self.P1, trans_a=True, kscale=pen_scale)
             self._mm(self.P1, W1, d.G('seq.0.weight'))
-            self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
-                     kscale=kscale[0:2 * n] if kscale is not None else None)
+            ks2 = kscale[0:2 * n] if kscale is not None else None
+            if self.sparse_d:
+                # data columns: product over the compact input into W1's layout; cond columns: sums of the
+                # (clip-scaled) delta rows by hot id, beside it, then transposed into place
+                with self._fork(1):
+                    self.dW1cT.zero_()
+                    ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT, rowscale=ks2)
+                self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2,
+                         seg_c=1, seg=self.seg)
+            else:
+                self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2)
         else:
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
             self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
         self._join()
+        if self.sparse_d:
+            C, Dd, gw = self.C, self.Dd, d.G('seq.0.weight')
+            ops.transpose_slices([(self.dW1cT[s * C:(s + 1) * C], gw[:, s * self.row + Dd:(s + 1) * self.row])
+                                  for s in range(self.pac)], accumulate=True)
         if update:
             self._disc_update(inj)
         if sub is None:
@@ -900,6 +975,8 @@ class StepEngine(object):
         ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=self.weight_clip if self.private else 0.0,
                       t_dev=d.t, t_host=1 + self._k, seg_off=seg_off, seg_add=seg_add, noise_scale=noise_scale,
                       noise_inj=noise_inj, rng=self.rng_shared, site=ops.SITE_NOISE_D + self._so)
+        if self.sparse_d:
+            self._refresh_w1ct()
 
     # ------------------------------------------------------------------------------------------
     # generator update
@@ -941,10 +1018,14 @@ class StepEngine(object):
         self._k = 0
         self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
-        self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3)
+        self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3, sel=c.sel if self.sparse_d else None)
         self._loss_dirty[1] = True
         self._disc_chain_down(n, self.rowscale_g)
-        self._mm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))       # d loss / d D-input
+        # d loss / d D-input (sparse_d: over the data columns only - nothing reads the gradient of the cond columns)
+        if self.sparse_d:
+            self._mm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0x), seg_b=2, seg=self.seg)
+        else:
+            self._mm(self.Dl[0][0:n], d.P('seq.0.weight'), self.dX.view(n, self.K0))
         ops.apply_activate_bwd(c.X[:, :self.Dd], self.dX[:, :self.Dd], self.dfake, self.spans, accumulate=self.has_cond)
         # generator backward: the input-gradient chain (dHg, BatchNorm backward, dX) on the main stream,
         # the weight / bias gradients of each layer beside it on the side streams

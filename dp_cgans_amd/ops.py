@@ -35,6 +35,13 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _stream_of(t):
+    global _dev_index
+    if t.is_cuda:
+        _dev_index = t.device.index
+    return _stream()
+
+
 def _stream():
     """The launch stream: the current stream of the GPU that holds the call's tensors.  Every wrapper
     below converts its tensors (``_p``) before it asks for the stream, so a call whose tensors live on
@@ -214,40 +221,47 @@ def cond_to_sel(cond, sel, bad=None):
     return sel
 
 
-def transpose_slices(pairs):
-    """pairs: [(src [r, c] view, dst [c, r] view)], up to 8; dst = src^T in one launch."""
-    L = len(pairs)
+def transpose_slices(pairs, accumulate=False):
+    """pairs: [(src [r, c] view, dst [c, r] view)]; dst (+)= src^T, 16 pairs per launch."""
     for s_, d_ in pairs:
         _chk(s_, torch.float32, 'src')
         _chk(d_, torch.float32, 'dst')
         if d_.shape[0] != s_.shape[1] or d_.shape[1] != s_.shape[0]:
             raise ValueError('transpose_slices: dst must be the transposed shape of src')
-    P = ctypes.c_void_p * L
-    I64 = ctypes.c_int64 * L
-    I32 = ctypes.c_int * L
-    lib().call('dpc_transpose_slices', L, P(*[s_.data_ptr() for s_, _ in pairs]), I64(*[_ld(s_) for s_, _ in pairs]),
-               I32(*[s_.shape[0] for s_, _ in pairs]), I32(*[s_.shape[1] for s_, _ in pairs]),
-               P(*[d_.data_ptr() for _, d_ in pairs]), I64(*[_ld(d_) for _, d_ in pairs]), _stream())
+    for i in range(0, len(pairs), 16):
+        grp = pairs[i:i + 16]
+        L = len(grp)
+        P = ctypes.c_void_p * L
+        I64 = ctypes.c_int64 * L
+        I32 = ctypes.c_int * L
+        lib().call('dpc_transpose_slices', L, P(*[s_.data_ptr() for s_, _ in grp]), I64(*[_ld(s_) for s_, _ in grp]),
+                   I32(*[s_.shape[0] for s_, _ in grp]), I32(*[s_.shape[1] for s_, _ in grp]),
+                   P(*[d_.data_ptr() for _, d_ in grp]), I64(*[_ld(d_) for _, d_ in grp]), int(accumulate), _stream_of(grp[0][0]))
 
 
-def hot_sort(sel, C, order, sid, n_items):
-    """Counting sort of the (row, hot id) pairs of sel [B, 2] by id -> order, sid [2B], n_items [1] (all int32)."""
-    for t, n in ((sel, 'sel'), (order, 'order'), (sid, 'sid'), (n_items, 'n_items')):
+def hot_sort(sel, C, order, sid, n_items, sel_b=None, pac=1):
+    """Counting sort of the (row, hot id) pairs of sel [B, 2] (and sel_b) by id -> order, sid, n_items [1] (all
+    int32); pac > 1: rows are groups of pac sub-rows, ids (b % pac) * C + sel (see dpc_hot_sort)."""
+    for t, n in ((sel, 'sel'), (sel_b, 'sel_b'), (order, 'order'), (sid, 'sid'), (n_items, 'n_items')):
         _chk(t, torch.int32, n)
     B = sel.shape[0]
-    if not sel.is_contiguous() or order.numel() < 2 * B or sid.numel() < 2 * B:
-        raise ValueError('hot_sort: sel must be contiguous [B, 2], order / sid hold 2B entries')
-    lib().call('dpc_hot_sort', _p(sel), B, int(C), _p(order), _p(sid), _p(n_items), _stream())
+    need = 2 * B * (2 if sel_b is not None else 1)
+    if not sel.is_contiguous() or order.numel() < need or sid.numel() < need:
+        raise ValueError('hot_sort: sel must be contiguous [B, 2], order / sid hold 2B entries per id table')
+    if sel_b is not None and (sel_b.shape != sel.shape or not sel_b.is_contiguous()):
+        raise ValueError('hot_sort: sel_b must match sel')
+    lib().call('dpc_hot_sort', _p(sel), _p(sel_b), B, int(pac), int(C), _p(order), _p(sid), _p(n_items), _stream())
 
 
-def hot_rows_sum(dy, order, sid, n_items, acc):
-    """acc[id] += sum of the rows of dy listed for id (sorted pairs of hot_sort)."""
+def hot_rows_sum(dy, order, sid, n_items, acc, rowscale=None, max_items=None):
+    """acc[id] += sum of the rows of dy (times rowscale[row]) listed for id (sorted pairs of hot_sort)."""
     _chk(dy, torch.float32, 'dy')
     _chk(acc, torch.float32, 'acc')
+    _chk(rowscale, torch.float32, 'rowscale')
     if acc.shape[1] != dy.shape[1]:
         raise ValueError('hot_rows_sum: shape mismatch')
-    lib().call('dpc_hot_rows_sum', _p(dy), _ld(dy), dy.shape[1], _p(order), _p(sid), _p(n_items), order.numel(), _p(acc),
-               _ld(acc), _stream())
+    lib().call('dpc_hot_rows_sum', _p(dy), _ld(dy), dy.shape[1], _p(order), _p(sid), _p(n_items),
+               int(max_items if max_items is not None else order.numel()), _p(acc), _ld(acc), _p(rowscale), _stream())
 
 
 def apply_activate_fwd(x, y, spans, exp_noise=None, rng=None, site=SITE_GUMBEL, tau=0.2):
@@ -335,9 +349,10 @@ def row_uniform(N, row_id, u_inj=None, rng=None, site=SITE_ROWPICK):
     return row_id
 
 
-def row_gather(table, row_id, out, Dd, sel=None, perm=None, C=0):
+def row_gather(table, row_id, out, Dd, sel=None, perm=None, C=0, sel_out=None):
+    _chk(sel_out, torch.int32, 'sel_out')
     lib().call('dpc_row_gather', _p(table), _ld(table), _p(row_id), row_id.shape[0], Dd, _p(out), _ld(out), _p(sel),
-               _p(perm), C, _stream())
+               _p(perm), C, _p(sel_out), _stream())
     return out
 
 
@@ -457,7 +472,8 @@ def gp_norm(g0, coef, pen_rows, nrm_out=None):
 
 
 def disc_first_layer_act(zpre, bias, n, H, S, alpha_inj=None, keep=None, rng=None, site_alpha=SITE_ALPHA,
-                         site_keep=SITE_DROP0, leak=0.2, alpha_out=None, stacked=True, clear=False):
+                         site_keep=SITE_DROP0, leak=0.2, alpha_out=None, stacked=True, clear=False, gat=None,
+                         sel_a=None, sel_b=None, pac=1, C=0):
     """H, S [3n, d] of the stacked rows [fake | real | interpolates] from zpre [2n, d] = x W1^T; not
     ``stacked``: H, S [n, d] from zpre [n, d].  ``clear``: zpre is zeroed once read."""
     _chk(keep, torch.uint8, 'keep')
@@ -467,9 +483,17 @@ def disc_first_layer_act(zpre, bias, n, H, S, alpha_inj=None, keep=None, rng=Non
         raise ValueError('disc_first_layer_act: zpre needs %dn rows, H and S %dn rows of the same width' % (zi, zo))
     if keep is not None and (keep.shape[0] != zo * n or keep.shape[1] != d):
         raise ValueError('disc_first_layer_act: keep must be [%dn, d]' % zo)
+    if gat is not None:
+        _chk(gat, torch.float32, 'gat')
+        _chk(sel_a, torch.int32, 'sel_a')
+        _chk(sel_b, torch.int32, 'sel_b')
+        if gat.shape[0] != pac * C or gat.shape[1] != d or sel_a.numel() != 2 * n * pac or \
+                (stacked and (sel_b is None or sel_b.numel() != 2 * n * pac)):
+            raise ValueError('disc_first_layer_act: gat must be [pac*C, d], the id tables [n*pac, 2]')
     lib().call('dpc_disc_first_layer_act', _p(zpre), _ld(zpre), _p(bias), n, d, _p(alpha_inj), _p(keep),
                _ld(keep) if keep is not None else 0, _p(rng), site_alpha, site_keep, leak, _p(H), _ld(H), _p(S), _ld(S),
-               _p(alpha_out), int(bool(stacked)), int(bool(clear)), _stream())
+               _p(alpha_out), int(bool(stacked)), int(bool(clear)), _p(gat), _ld(gat) if gat is not None else 0,
+               _p(sel_a), _p(sel_b), int(pac), int(C), _stream())
 
 
 def gp_gram_rows(T, u, slope, coef, pen_rows, f_out, v1, q_out=None, nrm_out=None):
@@ -525,7 +549,7 @@ def hook_noise(seg_add, fires, t_dev, inv_B, rng, site=SITE_HOOK, t_add=1):
 
 
 def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=None, norm_out=None, zpre=None,
-                       gp_f=None, gp_q=None, fc_out=None, clear_zpre=False):
+                       gp_f=None, gp_q=None, fc_out=None, clear_zpre=False, sel_a=None, sel_b=None, pac=1):
     """layers: [(delta [3n,d], act [3n,K])]; all Gram contractions and the clip factors in one launch.
     With ``zpre`` the penalty row of layer 0's act is implicit (act[0] needs only its first 2n rows):
     see dpc_persample_clip_all_gram."""
@@ -550,8 +574,10 @@ def persample_clip_all(layers, n, clip, gscale, norm2, rowc, roww=None, rowc_w=N
     else:
         if zpre.shape[0] != 2 * n or zpre.shape[1] != layers[0][0].shape[1]:
             raise ValueError('persample_clip_all: zpre must be [2n, d0]')
+        _chk(sel_a, torch.int32, 'sel_a')
+        _chk(sel_b, torch.int32, 'sel_b')
         lib().call('dpc_persample_clip_all_gram', *args, _p(zpre), _ld(zpre), _p(gp_f), _p(gp_q), _p(fc_out),
-                   int(bool(clear_zpre)), _stream())
+                   int(bool(clear_zpre)), _p(sel_a), _p(sel_b), int(pac), _stream())
 
 
 def condvec_original(table, cond_st, dims, matrix_st, cond, rows_inj=None, cols_inj=None, rng=None, site=SITE_CONDVEC):

@@ -169,10 +169,11 @@ int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const
 int dpc_row_uniform(int64_t N, const double* u_inj, const uint64_t* rng, uint32_t site, int64_t B,
                     int64_t* row_id, void* stream);
 /* self._data[idx] (data_sampler.py:396) + the cond vector that travels with it (c_pair_1[perm],
- * dp_cgan.py:607) written behind the row when sel != NULL. */
+ * dp_cgan.py:607): with sel != NULL its C columns are written behind the row (C may be 0) and / or its two
+ * hot ids to sel_out int32 [B][2] (nullable). */
 int dpc_row_gather(const float* table, int64_t ld, const int64_t* row_id, int64_t B, int Dd,
                    float* out, int64_t ldo, const int32_t* sel, const int64_t* perm, int C,
-                   void* stream);
+                   int32_t* sel_out, void* stream);
 /* np.random.shuffle(arange(B)) (dp_cgan.py:594-595) in distribution: a keyed Feistel bijection of
  * [0, 2^bits) cycle-walked into [0, B); keys_ws is unused (kept for ABI stability, may be NULL). */
 int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm, uint64_t* keys_ws,
@@ -184,20 +185,25 @@ int dpc_random_perm(const uint64_t* rng, uint32_t site, int64_t B, int64_t* perm
  * int32, nullable) counts rows that are not one-/two-hot {0,1} vectors. */
 int dpc_cond_to_sel(const float* cond, int64_t ld, int64_t B, int C, int32_t* sel, int32_t* bad,
                     void* stream);
-/* Up to 8 transposes in one launch, dst_k[c][r] = src_k[r][c]; all array arguments are HOST arrays of
- * nslices entries.  Keeps W[:, cond columns]^T of the generator layers current (gat of
- * dpc_gemm_f32_gather) and writes the cond-column gradients (dpc_hot_rows_sum) back in dW's layout. */
+/* Up to 16 transposes in one launch, dst_k[c][r] (+)= src_k[r][c]; all array arguments are HOST arrays of
+ * nslices entries.  Keeps W[:, cond columns]^T of the generator layers and of the discriminator's first layer
+ * current (gat of dpc_gemm_f32_gather / dpc_disc_first_layer_act) and writes the cond-column gradients
+ * (dpc_hot_rows_sum) back in dW's layout (accumulate != 0: added to what dW holds). */
 int dpc_transpose_slices(int nslices, const float* const* src, const int64_t* ld_src, const int* rows,
-                         const int* cols, float* const* dst, const int64_t* ld_dst, void* stream);
-/* Counting sort of the (row, hot id) pairs of sel int32 [B][2] by id: order[p] = row, sid[p] = id for
- * p < *n_items (device int32), ids ascending; order / sid hold 2B entries; C <= 15360. */
-int dpc_hot_sort(const int32_t* sel, int64_t B, int C, int32_t* order, int32_t* sid, int32_t* n_items,
-                 void* stream);
-/* acc[id][j] += sum of dy[row][j] over the sorted pairs: the cond columns of dW = dY^T X (autograd of
- * the Linear layers above), transposed [C][ld_acc].  One fp32 atomic per id change and block: not
- * bit-reproducible.  max_items = capacity of order / sid. */
+                         const int* cols, float* const* dst, const int64_t* ld_dst, int accumulate, void* stream);
+/* Counting sort of (row, hot id) pairs by id: order[p] = row, sid[p] = id for p < *n_items (device int32), ids
+ * ascending; order / sid hold 2B (4B with sel_b) entries.  Pairs come from sel_a (and sel_b, nullable) int32
+ * [B][2], negative = none.  pac > 1 groups the B sub-rows pac to a row as Discriminator.forward does
+ * (dp_cgan.py:66-68): sub-row b of table t gives row t*(B/pac) + b/pac and id (b % pac)*C + sel[b][h], the
+ * cond column inside the pac row.  Any number of ids (multi-block). */
+int dpc_hot_sort(const int32_t* sel_a, const int32_t* sel_b, int64_t B, int pac, int C, int32_t* order,
+                 int32_t* sid, int32_t* n_items, void* stream);
+/* acc[id][j] += sum of rowscale[row] * dy[row][j] over the sorted pairs (rowscale nullable = 1): the cond
+ * columns of dW = dY^T X (autograd of the Linear layers above), transposed [ids][ld_acc].  One fp32 atomic per
+ * id change and block: not bit-reproducible.  max_items = capacity of order / sid. */
 int dpc_hot_rows_sum(const float* dy, int64_t ld, int F, const int32_t* order, const int32_t* sid,
-                     const int32_t* n_items, int64_t max_items, float* acc, int64_t ld_acc, void* stream);
+                     const int32_t* n_items, int64_t max_items, float* acc, int64_t ld_acc,
+                     const float* rowscale, void* stream);
 
 /* ---- DataTransformer.transform (data_transformer.py:102-150) -------------------------------- */
 /* tab fp64 [4][K] = mu, sigma, precision_cholesky, A (A = the x-independent part of sklearn's
@@ -315,12 +321,19 @@ int dpc_gp_norm(float* g0, int64_t ld, int64_t n, int K0, float coef, double* pe
  * dpc_gemm_f32's epilogue 1 (keep u8 [3n, d] or Philox draw row*d + col of site_keep; alpha_inj [n]
  * or Philox draw r of site_alpha, as dpc_interpolate).  stacked == 0: zpre [n, d] -> H, S [n, d], the
  * plain Linear + LeakyReLU + Dropout of n rows.  clear_zpre != 0: every product is set to 0 once read,
- * so that the next split-K product can add into the buffer without a memset in front of it. */
+ * so that the next split-K product can add into the buffer without a memset in front of it.
+ * gat != NULL: the cond columns of the input (cat([data, cond]), dp_cgan.py:622-623) stayed off the matrix
+ * cores - zpre holds the products over the data columns only (segment-mapped GEMM) and every row adds, for
+ * each of its pac sub-rows s and each of that sub-row's (up to two) hot cond ids c, row s*C + c of
+ * gat = W1[:, cond columns]^T [pac*C][ldg]; sel_a int32 [n*pac][2] ids of the first block of rows (fake),
+ * sel_b of the second (real; stacked only), negative = none.  With clear_zpre == 0 the gathered share is
+ * also added to the stored zpre, which then holds x W1^T over all columns (dpc_persample_clip_all_gram reads it). */
 int dpc_disc_first_layer_act(float* zpre, int64_t ldz, const float* bias, int64_t n, int d,
                              const float* alpha_inj, const uint8_t* keep, int64_t ld_keep,
                              const uint64_t* rng, uint32_t site_alpha, uint32_t site_keep, float leak,
                              float* H, int64_t ldh, float* S, int64_t lds, float* alpha_out, int stacked,
-                             int clear_zpre, void* stream);
+                             int clear_zpre, const float* gat, int64_t ldg, const int32_t* sel_a,
+                             const int32_t* sel_b, int pac, int C, void* stream);
 /* calc_gradient_penalty (:55-62) through the first layer's Gram matrix G = W1 W1^T: with u [n, d] the
  * penalty rows of the first layer's backward delta and T = u G,  ||grad_xhat D||^2 = rowsum(T*u)
  * and the penalty rows of the next v-chain link are v1 = f*T*slope, f = coef*(nrm-1)/nrm.  Writes
@@ -362,13 +375,16 @@ int dpc_persample_clip_all(int nlayers, const float* const* delta, const int64_t
  * (dpc_gp_gram_rows): act[0] is [2n, K[0]] (fake and real rows only), zpre [2n, d[0]] the first
  * layer's plain products x W1^T, gp_f / gp_q the outputs of dpc_gp_gram_rows; the Gram entries of the
  * missing row are f_i*(u_i . zpre_i), f_i*(u_i . zpre_{n+i}) and f_i^2 * q_i.  fc_out[i] (nullable)
- * = c_i * gp_f[i].  clear_zpre != 0: zpre is set to 0 once read (see dpc_disc_first_layer_act). */
+ * = c_i * gp_f[i].  clear_zpre != 0: zpre is set to 0 once read (see dpc_disc_first_layer_act).
+ * sel_a != NULL: act[0] holds the DATA columns of the pac-row input only (zero padded) and the inner
+ * products of the rows' two-hot cond parts are counted from the hot ids, sel_a / sel_b int32 [n*pac][2] of
+ * the fake / real sub-rows (as in dpc_disc_first_layer_act). */
 int dpc_persample_clip_all_gram(int nlayers, const float* const* delta, const int64_t* ldd, const int* d,
                                 const float* const* act, const int64_t* lda, const int* K, int64_t n,
                                 float clip, float gscale, double* norm2, float* rowc, const float* roww,
                                 float* rowc_w, float* norm_out, float* zpre, int64_t ldz,
                                 const float* gp_f, const double* gp_q, float* fc_out, int clear_zpre,
-                                void* stream);
+                                const int32_t* sel_a, const int32_t* sel_b, int pac, void* stream);
 /* c_i = min(1, clip / (gscale*sqrt(norm2[i]))) -> rowc[p*n+i] (p = 0..2), rowc_w = rowc * roww
  * (nullable), norm_out[i] = gscale*sqrt(norm2[i]) (nullable). */
 int dpc_clip_factors(const double* norm2, int64_t n, float clip, float gscale, float* rowc,

@@ -602,6 +602,78 @@ def test_hot_sort_and_row_sums_are_the_cond_block_of_the_weight_gradient(ops, B,
     assert float(dW[:, :11].min()) == 7.0
 
 
+@pytest.mark.parametrize('n,pac,C,d0', [(50, 10, 38, 128), (1024, 8, 276, 256), (7, 3, 5, 21), (64, 8, 18000, 64), (2100, 8, 276, 32)])
+def test_discriminator_cond_block_as_gathers_and_sorted_row_sums(ops, n, pac, C, d0):
+    """The cond columns of the discriminator's first layer (cat([data, cond]) per sub-row, pac sub-rows to a
+    row: dp_cgan.py:66-68, 622-623) off the matrix cores.  Forward: dpc_disc_first_layer_act adds the hot rows
+    of W1cT to the data-column products, == the dense product over the cond columns.  Weight gradient: the pac-
+    grouped two-table sort + clip-scaled row sums == dY^T [cond_fake; cond_real] (C beyond the old one-block
+    sort's 15360 ids and more pairs than the register path holds included)."""
+    g = torch.Generator().manual_seed(n + C)
+    d_ = dev()
+    B = n * pac
+
+    def ids():
+        a = torch.randint(0, C, (B,), generator=g)
+        b = (a + 1 + torch.randint(0, C - 1, (B,), generator=g)) % C
+        sel = torch.stack([a, b], 1).to(torch.int32)
+        sel[torch.rand(B, generator=g) < 0.1, 1] = -1           # one-hot sub-rows
+        sel[0] = -1                                             # a sub-row without cond
+        return sel
+    sel_f, sel_r = ids(), ids()
+
+    def dense(sel):                                             # [n, pac*C] two-hot rows
+        x = torch.zeros(B, C, dtype=torch.float64)
+        for h in range(2):
+            ok = sel[:, h] >= 0
+            x[torch.arange(B)[ok], sel[ok, h].long()] += 1
+        return x.reshape(n, pac * C)
+    Xf, Xr = dense(sel_f), dense(sel_r)
+    # ---- forward
+    W1c = torch.randn(d0, pac * C, generator=g) * 0.1           # cond columns of W1, sub-row major
+    gat = W1c.t().contiguous().to(d_)
+    zdata = torch.randn(2 * n, d0, generator=g)                 # stands for the data-column products
+    bias = torch.randn(d0, generator=g) * 0.1
+    alpha = torch.rand(n, generator=g)
+    keep = (torch.rand(3 * n, d0, generator=g) > 0.5).to(torch.uint8)
+    full = zdata.double() + torch.cat([Xf, Xr]) @ W1c.double().t()
+    outs = []
+    for stacked_gat in (False, True):
+        z = (full.float() if not stacked_gat else zdata).clone().to(d_)
+        H, S = torch.empty(3 * n, d0, device=d_), torch.empty(3 * n, d0, device=d_)
+        kw = dict(gat=gat, sel_a=sel_f.to(d_), sel_b=sel_r.to(d_), pac=pac, C=C) if stacked_gat else {}
+        ops.disc_first_layer_act(z, bias.to(d_), n, H, S, alpha_inj=alpha.to(d_), keep=keep.to(d_), **kw)
+        outs.append((H, S, z))
+    (H0, S0, _), (H1, S1, z1) = outs
+    close(H1, H0, what='H with gathered cond columns')
+    assert float((S1 != S0).float().mean()) < 1e-3              # slopes flip only where a pre-activation is within rounding of 0
+    close(z1, full, what='products written back for the Gram kernel')
+    # ---- weight gradient
+    dy = torch.randn(2 * n, d0, generator=g)
+    ks = torch.rand(2 * n, generator=g)
+    ref = (dy * ks[:, None]).double().t() @ torch.cat([Xf, Xr])          # [d0, pac*C]
+    order = torch.full((4 * B,), -1, dtype=torch.int32, device=d_)
+    sid = torch.full((4 * B,), -1, dtype=torch.int32, device=d_)
+    n_items = torch.zeros(1, dtype=torch.int32, device=d_)
+    ops.hot_sort(sel_f.to(d_), C, order, sid, n_items, sel_b=sel_r.to(d_), pac=pac)
+    m = int(n_items)
+    assert m == int((sel_f >= 0).sum() + (sel_r >= 0).sum())
+    ss = sid.cpu()[:m].long()
+    assert bool((ss[1:] >= ss[:-1]).all()) and int(ss.max()) < pac * C
+    acc = torch.zeros(pac * C, d0, device=d_)
+    ops.hot_rows_sum(dy.to(d_), order, sid, n_items, acc, rowscale=ks.to(d_))
+    close(acc, ref.t(), what='cond columns of dW1', rtol=2e-5)
+    # transposed and ADDED into dW1's layout [d0, pac * (Dd + C)]
+    Dd = 3
+    row = Dd + C
+    base = torch.randn(d0, pac * row, generator=g)
+    dW = base.clone().to(d_)
+    ops.transpose_slices([(acc[s_ * C:(s_ + 1) * C], dW[:, s_ * row + Dd:(s_ + 1) * row]) for s_ in range(pac)], accumulate=True)
+    want = base.double().reshape(d0, pac, row).clone()
+    want[:, :, Dd:] += ref.reshape(d0, pac, C)
+    close(dW, want.reshape(d0, pac * row), what='accumulated into dW1', rtol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm pieces
 # ------------------------------------------------------------------------------------------------

@@ -2,8 +2,8 @@
 """Timeline of ONE graph-replayed training step from a rocprofv3 --kernel-trace CSV.
 
 usage: step_timeline.py <..._kernel_trace.csv> [step index from the end, default 3]
-A step ends with rng_advance_kernel.  Prints every kernel of the step with its start offset, duration
-and queue, then the time during which 0 / 1 / 2+ kernels were running."""
+A step ends with rng_advance_kernel.  Prints every kernel of the step with its start offset, duration,
+queue and grid (blocks), then the time during which 0 / 1 / 2+ kernels were running."""
 import csv
 import sys
 
@@ -14,17 +14,18 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?')))
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?'),
+                         int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), int(r['Grid_Size_Y'])))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if r[2].startswith('rng_advance_kernel')]
     lo, hi = ends[-back - 1] + 1, ends[-back] + 1
     step = rows[lo:hi]
     t0 = rows[lo - 1][1]                     # end of the previous step's last kernel
     print('step of %d kernels, %.1f us from the end of the previous step to its own end' % (len(step), (step[-1][1] - t0) / 1e3))
-    for s, e, name, q in step:
-        short = name.split('(')[0].replace('void ', '')[:60]
-        print('%9.1f %8.1f  q%-3s %s' % ((s - t0) / 1e3, (e - s) / 1e3, q, short))
-    ev = sorted([(s, 1) for s, e, _, _ in step] + [(e, -1) for s, e, _, _ in step])
+    for s, e, name, q, gx, gy in step:
+        short = name.split('(')[0].replace('void ', '')[:48]
+        print('%8.1f %7.1f q%-2s %-48s %5d %3d' % ((s - t0) / 1e3, (e - s) / 1e3, q, short, gx, gy))
+    ev = sorted([(s, 1) for s, e, *_ in step] + [(e, -1) for s, e, *_ in step])
     busy = {0: 0, 1: 0, 2: 0}
     depth, last = 0, t0
     for t, d in ev:
