@@ -60,6 +60,10 @@ struct GemmArgs {
   //            straddles segments);  seg_b 2: along N of an n-contiguous B (input gradient dy W1);
   //   seg_c 1: along N of C (weight gradient dy^T x into W1's layout; entries beyond seg_len are not stored).
   int seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
+  // optional column statistics of the result (before beta * C): colstat[n] += sum_m v, colstat[N + n] += sum_m v^2
+  // with fp64 atomics - BatchNorm1d's batch statistics taken where the Linear's output tile still sits in
+  // registers (dp_cgan.py:75-76).  fp32 sums over the 32 rows of an MFMA tile, fp64 across tiles.
+  double* colstat;
 };
 
 // stored index minus compact index
@@ -388,6 +392,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
       live = live && (col - sgm * g.seg_pad) < g.seg_len;
       ocol = col + (int64_t)sgm * (g.seg_stride - g.seg_pad);
     }
+    float cs0 = 0.f, cs1 = 0.f;
     if (live) {
       const float bv = (g.bias && add_bias) ? g.bias[col] : 0.f;
 #pragma unroll
@@ -400,6 +405,8 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
             atomicAdd(cp, v);
           } else {
             if (gather) v += lds[(row - m0) * BN + (col - n0)];
+            cs0 += v;
+            cs1 += v * v;
             if (g.epi == EPI_LEAKY_DROPOUT) {
               float keep;
               if (g.keep) {
@@ -419,6 +426,14 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
             *cp = v;
           }
         }
+      }
+    }
+    if (g.colstat) {             // (block-uniform; both lane halves hold the same column)
+      cs0 += __shfl_xor(cs0, 32, 64);
+      cs1 += __shfl_xor(cs1, 32, 64);
+      if (lk == 0 && live) {
+        atomicAdd(g.colstat + col, (double)cs0);
+        atomicAdd(g.colstat + g.N + col, (double)cs1);
       }
     }
   };
@@ -537,6 +552,9 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   g.b_vec = (((uintptr_t)d.B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   // segment maps (GemmArgs::seg_*)
   g.seg_b = d.seg_b; g.seg_c = d.seg_c; g.seg_len = d.seg_len; g.seg_pad = d.seg_pad; g.seg_stride = d.seg_stride;
+  g.colstat = d.colstat;
+  DPC_CHECK_ARG(!d.colstat || (epi == EPI_NONE && !d.seg_c && (d.splitk == 0 || d.splitk == 1)),
+                "gemm: column statistics go with epilogue none, a plain C and no split-K");
   if (d.seg_b || d.seg_c) {
     DPC_CHECK_ARG(d.seg_b >= 0 && d.seg_b <= 2 && (d.seg_c == 0 || d.seg_c == 1), "gemm: unknown segment map");
     DPC_CHECK_ARG(d.seg_pad > 0 && d.seg_len > 0 && d.seg_len <= d.seg_pad && d.seg_stride >= d.seg_len, "gemm: bad segment map");
@@ -566,7 +584,7 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   g.tiles_n = (int)dpc_cdiv(N, bn);
   const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
   bool deferred_epi = false;
-  int splitk = d.splitk;
+  int splitk = d.colstat ? 1 : d.splitk;
   if (splitk <= 0) {
     // auto.  Cost model fitted to MI355X measurements of the 64x64 tile (tools/gemm_occupancy.py,
     // tools/gemm_split_sweep.py): a CU works through its resident blocks at 17.5 ns per k and block

@@ -96,6 +96,102 @@ extern "C" int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int6
   return DPC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several weighted column sums in two launches (partials for all, finish for all): out_p[f] (+)= sum_r
+// w_p[r] * x_p[r, f].  The bias gradients and the head-layer weight gradient of a network's backward pass are
+// such sums over different matrices; one launch pair for all of them instead of one per sum (a kernel node
+// costs ~5 us whatever it does).  Same kernels' arithmetic and order as dpc_colreduce_partial(mode 1) +
+// dpc_colreduce_finish(kind 1) per problem: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+#define DPC_MAX_COLSUMS 8
+struct MultiColArgs {
+  const float* x[DPC_MAX_COLSUMS]; int64_t ldx[DPC_MAX_COLSUMS]; int64_t rows[DPC_MAX_COLSUMS]; int F[DPC_MAX_COLSUMS];
+  const float* w[DPC_MAX_COLSUMS]; float* out[DPC_MAX_COLSUMS]; int R[DPC_MAX_COLSUMS];
+  int blk0[DPC_MAX_COLSUMS + 1];        // first block of problem p in the partial launch (strips * R blocks each)
+  int fin0[DPC_MAX_COLSUMS + 1];        // ... in the finish launch (strips blocks each)
+  int64_t part0[DPC_MAX_COLSUMS];       // offset of problem p's partials
+  double* part; int n; int accumulate;
+};
+
+__global__ __launch_bounds__(256) void colsum_multi_partial_kernel(MultiColArgs a) {
+  __shared__ double red[4][64];
+  int p = 0;
+  while (p + 1 < a.n && (int)blockIdx.x >= a.blk0[p + 1]) ++p;
+  const int local = blockIdx.x - a.blk0[p];
+  const int strips = (a.F[p] + 63) / 64;
+  const int strip = local % strips, chunk = local / strips;
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = strip * 64 + c;
+  const int64_t per = (a.rows[p] + a.R[p] - 1) / a.R[p];
+  const int64_t r0 = (int64_t)chunk * per, r1 = min(a.rows[p], r0 + per);
+  const float* __restrict__ x = a.x[p];
+  const float* __restrict__ w = a.w[p];
+  const int64_t ld = a.ldx[p];
+  double s0 = 0.0;
+  if (f < a.F[p]) {
+#pragma unroll 8
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float v = x[r * ld + f];
+      s0 += (double)(w ? w[r] * v : v);
+    }
+  }
+  red[rl][c] = s0;
+  __syncthreads();
+  if (rl == 0 && f < a.F[p])
+    a.part[a.part0[p] + (int64_t)chunk * a.F[p] + f] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ __launch_bounds__(256) void colsum_multi_finish_kernel(MultiColArgs a) {
+  __shared__ double red[4][64];
+  int p = 0;
+  while (p + 1 < a.n && (int)blockIdx.x >= a.fin0[p + 1]) ++p;
+  const int strip = blockIdx.x - a.fin0[p];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = strip * 64 + c;
+  const int F = a.F[p], R = a.R[p];
+  const double* __restrict__ part = a.part + a.part0[p];
+  double s0 = 0.0;
+  if (f < F) {
+#pragma unroll 8
+    for (int r = rl; r < R; r += 4) s0 += part[(int64_t)r * F + f];
+  }
+  red[rl][c] = s0;
+  __syncthreads();
+  if (rl != 0 || f >= F) return;
+  s0 = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  a.out[p][f] = a.accumulate ? a.out[p][f] + (float)s0 : (float)s0;
+}
+
+// x / ldx / rows / F / w / out: HOST arrays of n (<= 8) entries (w[p] nullable = all ones); part: fp64 workspace
+// of part_cap elements (sum over p of R_p * F_p, R_p <= 64, is enough: 64 * sum F always is).
+extern "C" int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
+                                const float* const* w, float* const* out, int accumulate, double* part,
+                                int64_t part_cap, void* stream) {
+  DPC_CHECK_ARG(n >= 1 && n <= DPC_MAX_COLSUMS, "colsum_multi: 1..8 sums");
+  DPC_CHECK_ARG(x && ldx && rows && F && w && out && part, "colsum_multi: null pointer");
+  MultiColArgs a;
+  a.n = n; a.part = part; a.accumulate = accumulate ? 1 : 0;
+  int blk = 0, fin = 0;
+  int64_t off = 0;
+  for (int p = 0; p < n; ++p) {
+    DPC_CHECK_ARG(x[p] && out[p] && rows[p] > 0 && F[p] > 0 && ldx[p] >= F[p], "colsum_multi: bad problem");
+    a.x[p] = x[p]; a.ldx[p] = ldx[p]; a.rows[p] = rows[p]; a.F[p] = F[p]; a.w[p] = w[p]; a.out[p] = out[p];
+    a.R[p] = pick_R(rows[p], F[p], 64);
+    const int strips = (int)dpc_cdiv(F[p], 64);
+    a.blk0[p] = blk; a.fin0[p] = fin; a.part0[p] = off;
+    blk += strips * a.R[p];
+    fin += strips;
+    off += (int64_t)a.R[p] * F[p];
+  }
+  a.blk0[n] = blk; a.fin0[n] = fin;
+  DPC_CHECK_ARG(off <= part_cap, "colsum_multi: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_multi_partial_kernel, dim3((unsigned)blk), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(colsum_multi_finish_kernel, dim3((unsigned)fin), dim3(256), 0, st, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
 // BatchNorm1d statistics from the column sums, and the running-statistics update
 // running = (1 - momentum) * running + momentum * new.  One function with FMA contraction off: both
 // kernels that apply it (colreduce_finish_kernel and the fused BatchNorm forward) must agree to the bit.

@@ -107,6 +107,19 @@ def _linear_init(w, b, gen):
     b.copy_((torch.rand(b.shape, generator=gen) * 2 - 1) * bound)
 
 
+def _zero_pool(spec, device):
+    """One byte buffer (zeroed by a single fill) carved into typed tensors: spec = [(name, shape, dtype)]
+    -> (buffer, {name: tensor}); every tensor starts on a 256-byte boundary."""
+    off, places = 0, []
+    for name, shape, dtype in spec:
+        nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        places.append((name, shape, dtype, off, nbytes))
+        off += (nbytes + 255) // 256 * 256
+    buf = torch.zeros(max(off, 256), dtype=torch.uint8, device=device)
+    views = {name: buf[o:o + nb].view(dtype).view(shape) for name, shape, dtype, o, nb in places}
+    return buf, views
+
+
 class NoDist(object):
     world = 1
     rank = 0
@@ -147,7 +160,8 @@ class GenContext(object):
         maxF = max(eng.gdim + [1])
         # one BatchNorm-sum workspace per layer (the deferred running-statistics update re-reads them)
         self.part = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in eng.gdim]
-        self.part_R = [0] * len(eng.gdim)
+        self.sums = [None] * len(eng.gdim)       # (workspace, row chunks) of the latest forward's BatchNorm sums
+        self.bnacc = None                        # fp64 [2, F] accumulators per layer (inside the engine's zero pools)
 
 
 class StepEngine(object):
@@ -192,6 +206,7 @@ class StepEngine(object):
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
         self._early_hook = None
+        self.early_at = os.environ.get('DPCGAN_EARLY_AT', 'd_forward')     # where train_step forks the generator update's forward
         self._inline = False
         self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
         d = self.dev
@@ -222,20 +237,28 @@ class StepEngine(object):
         # ids into dWcT[l] (zeroed with the gradient buffer: one fill), then transposed into place.
         if sparse_cond is None:
             sparse_cond = StepEngine.SPARSE_COND
-        self.sparse_cond = self.nd > 0 and self.C <= 15360 and (True if sparse_cond is None else bool(sparse_cond))
+        self.sparse_cond = self.nd > 0 and (True if sparse_cond is None else bool(sparse_cond))
         outs = self.gdim + [self.Dd]
         if self.sparse_cond:
-            ext = [(self.C * w + 3) // 4 * 4 for w in outs]
-            gx = torch.zeros(self.gen.n + sum(ext), device=d)
-            self.gen.g = gx[:self.gen.n]
-            self._gen_gx = gx
-            self.dWcT, off = [], self.gen.n
-            for w, e in zip(outs, ext):
-                self.dWcT.append(gx[off:off + self.C * w].view(self.C, w))
-                off += e
             self.WcT = [torch.zeros(self.C, (w + 3) // 4 * 4, device=d)[:, :w] for w in outs]     # rows 16-byte aligned
-        else:
-            self._gen_gx = self.gen.g
+        # BatchNorm's column sums are taken in the Linear's GEMM epilogue (fp64 atomics into [2, F] accumulators:
+        # GemmArgs::colstat) unless the engine runs in reproducible mode (separate fixed-order reduction)
+        self.fused_stats = not self.deterministic
+        # Everything the generator update accumulates into lies in ONE buffer that one fill zeroes (_g_front):
+        # the flat gradient (split-K products add with beta = 1), the transposed cond-column gradients, the
+        # BatchNorm statistics accumulators of the update's forward (and of both forwards of a data-parallel
+        # step: `pair` holds [layer][context][2, F] so that one all-reduce per layer serves both).
+        spec = [('g', (self.gen.n,), torch.float32)]
+        if self.sparse_cond:
+            spec += [('dWcT%d' % i, (self.C, w), torch.float32) for i, w in enumerate(outs)]
+        spec += [('bn%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
+        spec += [('pair%d' % l, (2, 2 * w), torch.float64) for l, w in enumerate(self.gdim)]
+        self._gen_gx, gv = _zero_pool(spec, d)
+        self.gen.g = gv['g']
+        if self.sparse_cond:
+            self.dWcT = [gv['dWcT%d' % i] for i in range(len(outs))]
+        self._bn_g = [gv['bn%d' % l] for l in range(L)]
+        self._bn_pair = [gv['pair%d' % l] for l in range(L)]
         self._wct_stale = True
         ds, k = [], self.K0
         for i, w in enumerate(self.ddim):
@@ -296,7 +319,7 @@ class StepEngine(object):
         self._losses = torch.zeros(4, **f32)         # loss_d, pen, -mean(y_fake), cond loss (see `losses`)
         self._loss_dirty = [False, False]            # D part / G part to be reduced from y, pen_rows, part_loss
         self._ce_parts = 0
-        maxF = max(self.gdim + self.ddim + [self.Dd, 1])
+        maxF = sum(self.gdim) + sum(self.ddim) + self.Dd + 2      # (one launch pair sums several matrices: ops.colsum_multi)
         self.part = torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64)
         # Independent kernels of a step (the real-row sampling chain beside the generator forward, the
         # weight-gradient GEMMs beside the input-gradient chain) run on side streams; inside a captured
@@ -325,18 +348,29 @@ class StepEngine(object):
         # loss_d reaches [observed on the reference: 11 draws per hook set for 6 tensors]
         self.hook_fires = torch.tensor([2.0] * (len(self.disc.keys) - 1) + [1.0], **f32)
         d0 = self.ddim[0]
+        # What the discriminator update accumulates into, zeroed by one fill at its start (_draw_inputs): the flat
+        # gradient, the transposed cond-column gradient of the first layer, the Gram-form penalty's small
+        # products (split-K adds with beta = 1, no memset nodes) and the BatchNorm accumulators of its forward.
+        ldw = (d0 + 3) // 4 * 4
+        spec = [('g', (self.disc.n,), torch.float32), ('P1', (d0, d0), torch.float32), ('G1', (d0, d0), torch.float32)]
         if self.sparse_d:
-            ldw = (d0 + 3) // 4 * 4
+            spec.append(('dW1cT', (pac * self.C, ldw), torch.float32))
+        spec += [('bn%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
+        self._disc_gx, dv = _zero_pool(spec, d)
+        self.disc.g = dv['g']
+        self._bn_d = [dv['bn%d' % l] for l in range(L)]
+        self.cd.bnacc, self.cg.bnacc = self._bn_d, self._bn_g
+        if self.sparse_d:
             self.W1cT = torch.zeros(pac * self.C, ldw, **f32)[:, :d0]       # W1[:, cond columns]^T, sub-row major
-            self.dW1cT = torch.zeros(pac * self.C, ldw, **f32)[:, :d0]      # its gradient (sorted row sums)
+            self.dW1cT = dv['dW1cT'][:, :d0]                                # its gradient (sorted row sums)
             self.sel_real = torch.full((B, 2), -1, device=d, dtype=torch.int32)   # hot ids that travel with the real rows
             self.order_d = torch.zeros(4 * B, device=d, dtype=torch.int32)  # (row, id) pairs of both blocks sorted by id
             self.sid_d = torch.zeros(4 * B, device=d, dtype=torch.int32)
             self.n_items_d = torch.zeros(1, device=d, dtype=torch.int32)
         self.Zp = torch.zeros(2 * n, d0, **f32)        # first layer's plain products of the fake and real rows
-        self.G1 = torch.zeros(d0, d0, **f32)           # W1 W1^T
+        self.G1 = dv['G1']                             # W1 W1^T
         self.Tq = torch.zeros(n, d0, **f32)            # u G1
-        self.P1 = torch.zeros(d0, d0, **f32)           # u^T diag(f c) u
+        self.P1 = dv['P1']                             # u^T diag(f c) u
         self.gp_f = torch.zeros(n, **f32)
         self.gp_fc = torch.zeros(n, **f32)
         self.gp_q = torch.zeros(n, device=d, dtype=torch.float64)
@@ -453,6 +487,8 @@ class StepEngine(object):
         """z, cond vector (+ mask) and, for the discriminator update, the real rows."""
         zv, cv = self._zc(c)
         B, Dd, C = self.B, self.Dd, self.C
+        if need_real:
+            self._disc_gx.zero_()      # the discriminator update's accumulators (gradients, Gram products, BatchNorm sums)
         # the latent draw stays on the main stream, in front of the cond-vector sampling: forked beside it,
         # the fork / join pair cost more than the 5 us kernel it hid (0.958 -> 0.950 ms per step)
         if 'z' in inj:
@@ -517,7 +553,7 @@ class StepEngine(object):
                 # W1 W1^T of the Gram-form penalty (see _d_back): issued here, beside the generator forward's
                 # chain of small kernels, rather than beside the discriminator's first-layer product
                 W1 = self.disc.P('seq.0.weight')
-                self._mm(W1, W1, self.G1, trans_b=True)
+                self._mm(W1, W1, self.G1, trans_b=True, beta=1.0)
                 self._g1_issued = True
 
     def _gen_weight(self, l):
@@ -529,23 +565,23 @@ class StepEngine(object):
             ops.transpose_slices([(self._gen_weight(l)[:, -self.C:], self.WcT[l]) for l in range(self.L + 1)])
         self._wct_stale = False
 
-    def _gen_linear(self, c, l, out, bias):
-        """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear)."""
+    def _gen_linear(self, c, l, out, bias, colstat=None):
+        """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear); ``colstat``: fp64 [2, F] accumulator
+        that receives the column sums / sums of squares of ``out`` in the same launch (BatchNorm statistics)."""
         W = self._gen_weight(l)
         if not self.sparse_cond:
-            self._mm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias)
+            self._mm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias, colstat=colstat)
             return
         if self._wct_stale or self.gen.loaded:       # parameters were (re)loaded outside an optimiser step
             self.gen.loaded = False
             self._refresh_wct()
         self._mm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
-                        bias=bias)
+                        bias=bias, colstat=colstat)
 
-    def _gen_dweight(self, c, l, dy, part, what=3):
+    def _gen_dweight(self, c, l, dy, what=3):
         """dW_l (+)= dy^T Hg[:, start[l]:] into the zeroed gradient buffer (``what`` & 1: the product over the
-        dense input columns; & 2: the cond columns' row sums and the bias gradient)."""
+        dense input columns; & 2: the cond columns' row sums).  Bias gradients: _gen_bias_grads."""
         gw = self.gen.G('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
-        gb = self.gen.G('seq.%d.fc.bias' % l if l < self.L else 'seq.%d.bias' % self.L)
         if self.sparse_cond and not self.deterministic:
             if what & 1:
                 self._mm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
@@ -553,21 +589,33 @@ class StepEngine(object):
                 ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
         elif what & 1:
             self._mm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
-        if what & 2:
-            self._colsum(dy, gb.view(1, -1), part=part)
+
+    def _gen_bias_grads(self, part):
+        """Bias gradients of every generator Linear (column sums of dfake and the dZ_l) in one launch pair."""
+        L = self.L
+        probs = [(self.dZ[l], None, self.gen.G('seq.%d.fc.bias' % l)) for l in range(L)]
+        probs.append((self.dfake, None, self.gen.G('seq.%d.bias' % L)))
+        ops.colsum_multi(probs, part)
+
+    def _bn_sums(self, c, l, acc):
+        """BatchNorm column sums of c.Z[l] for the fused normalisation kernel: -> (workspace, row chunks).  With
+        fused statistics the Linear's epilogue has left the finished [2, F] sums in ``acc`` already."""
+        if self.fused_stats:
+            return acc, 1
+        R = ops.colreduce_partial(0, c.Z[l], c.part[l])
+        return c.part[l], R
 
     def _gen_forward(self, c, running=True):
         """Generator forward into context ``c``.  ``running`` False leaves BatchNorm's running
-        statistics alone (``_bn_running`` applies the update later, from the column sums kept in c.part)."""
+        statistics alone (``_bn_running`` applies the update later, from the column sums kept for it)."""
         g = self.gen
         count = float(self.gB)
         for l in range(self.L):
-            self._gen_linear(c, l, c.Z[l], g.P('seq.%d.fc.bias' % l))
-            R = ops.colreduce_partial(0, c.Z[l], c.part[l])
-            c.part_R[l] = R
-            nel = R * 2 * self.gdim[l]
-            self._allreduce(c.part[l][:nel])
-            ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], c.part[l], R, count,
+            self._gen_linear(c, l, c.Z[l], g.P('seq.%d.fc.bias' % l), colstat=c.bnacc[l] if self.fused_stats else None)
+            part, R = self._bn_sums(c, l, c.bnacc[l])
+            c.sums[l] = (part, R)
+            self._allreduce(part[:R * 2 * self.gdim[l]])
+            ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], part, R, count,
                                   g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l], c.bn_invstd[l],
                                   run_mean=self.bn_run['seq.%d.bn.running_mean' % l] if running else None,
                                   run_var=self.bn_run['seq.%d.bn.running_var' % l] if running else None)
@@ -578,7 +626,8 @@ class StepEngine(object):
     def _gen_forward_pair(self, ca, cb, so_a, so_b):
         """Two generator forwards in lockstep (the last discriminator update's and the generator
         update's: same weights, different inputs) for data-parallel steps, activations included: the
-        BatchNorm column sums of both go into ONE buffer and ONE all-reduce per layer instead of two.
+        BatchNorm column sums of both lie in ONE buffer ([context][2, F], finished sums) and take ONE
+        all-reduce per layer instead of two.
         Same arithmetic and the same running-statistics order (ca then cb) as two _gen_forward calls.
         The two are independent chains of small kernels, so cb's runs on the `early` stream beside ca's
         (joined at every collective); cb's last Linear and activation are left running there when this
@@ -607,34 +656,29 @@ class StepEngine(object):
         for l in range(self.L):
             F = self.gdim[l]
             b = g.P('seq.%d.fc.bias' % l)
-            Rc = self._pair_R.get(l)
-            if Rc is None or not lanes:
-                # first call (R, the number of row chunks of the reduction, is not known yet): one after the other
-                if lanes:
-                    main.wait_stream(self.early)
-                R = 0
-                for i, c in enumerate((ca, cb)):      # same shape, hence the same R: the two sets lie back to back
-                    self._gen_linear(c, l, c.Z[l], b)
-                    R = ops.colreduce_partial(0, c.Z[l], self.pair_part[i * R * 2 * F:])
-                self._pair_R[l] = R
-                if lanes:
-                    self.early.wait_stream(main)
+            if self.fused_stats:
+                acc = self._bn_pair[l]              # [2 contexts][2F] finished sums (zeroed with the gradient pool)
+                R, width = 1, 2 * F
+                sums = [acc[0], acc[1]]
             else:
-                R = Rc
-                with lane_b():
-                    self._gen_linear(cb, l, cb.Z[l], b)
-                    Rb = ops.colreduce_partial(0, cb.Z[l], self.pair_part[R * 2 * F:])
-                self._gen_linear(ca, l, ca.Z[l], b)
-                Ra = ops.colreduce_partial(0, ca.Z[l], self.pair_part)
-                assert Ra == R and Rb == R
+                R = ops.colreduce_rows(self.B, F)
+                width = R * 2 * F
+                sums = [self.pair_part[0:width], self.pair_part[width:2 * width]]
+            with lane_b():
+                self._gen_linear(cb, l, cb.Z[l], b, colstat=sums[1] if self.fused_stats else None)
+                if not self.fused_stats:
+                    assert ops.colreduce_partial(0, cb.Z[l], sums[1]) == R
+            self._gen_linear(ca, l, ca.Z[l], b, colstat=sums[0] if self.fused_stats else None)
+            if not self.fused_stats:
+                assert ops.colreduce_partial(0, ca.Z[l], sums[0]) == R
+            if lanes:
                 main.wait_stream(self.early)
-            self._allreduce(self.pair_part[:2 * R * 2 * F])
+            self._allreduce(self._bn_pair[l].view(-1) if self.fused_stats else self.pair_part[:2 * width])
             for i, c in enumerate((ca, cb)):
                 if i == 1 and lanes:
                     self.early.wait_stream(main)     # after ca's: the running statistics are updated in sequence order
                 with (lane_b() if i == 1 else contextlib.nullcontext()):
-                    ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]],
-                                          self.pair_part[i * R * 2 * F:(i + 1) * R * 2 * F], R, count,
+                    ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], sums[i], R, count,
                                           g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l],
                                           c.bn_invstd[l], run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
                                           run_var=self.bn_run['seq.%d.bn.running_var' % l])
@@ -660,7 +704,8 @@ class StepEngine(object):
         the sequence of forwards (momentum updates do not commute)."""
         count = float(self.gB)
         for l in range(self.L):
-            ops.colreduce_finish(c.part[l], c.part_R[l], 2, self.gdim[l], 0, self.bn_scratch[l][0], self.bn_scratch[l][1],
+            part, R = c.sums[l]
+            ops.colreduce_finish(part, R, 2, self.gdim[l], 0, self.bn_scratch[l][0], self.bn_scratch[l][1],
                                  count=count, run_mean=self.bn_run['seq.%d.bn.running_mean' % l],
                                  run_var=self.bn_run['seq.%d.bn.running_var' % l])
         self.bn_batches += 1
@@ -856,6 +901,8 @@ class StepEngine(object):
         n, B, M, d = self.n, self.B, self.M, self.disc
         self._last = self.cd
         self._join()
+        if self._early_hook is not None and self.early_at == 'd_forward':      # see train_step
+            self._early_hook()
         W1 = d.P('seq.0.weight')
         gp_rows = slice(2 * n, 3 * n)
         gram = self.gp_gram
@@ -868,7 +915,7 @@ class StepEngine(object):
             # shrink from 3n to 2n rows (forward, weight gradient) or disappear (g0, v1).
             if not self._g1_issued:
                 with self._fork(0):
-                    self._mm(W1, W1, self.G1, trans_b=True)
+                    self._mm(W1, W1, self.G1, trans_b=True, beta=1.0)
             self._g1_issued = False
             self._disc_forward_stacked(inj)
         else:
@@ -914,36 +961,39 @@ class StepEngine(object):
                 ops.persample_clip_all(layers, n, self.dp_clip, float(self.gn), self.norm2, self.rowc,
                                        roww=self.rowscale_d, rowc_w=self.rowc_w, norm_out=self.norms)
             kscale, w_last, w_bias = self.rowc, self.rowc_w, self.rowc[0:2 * n]
-        # weight gradients: the first layer's product (K0 wide) on the main stream, everything else beside it
-        with self._fork(0) as part:
+        # Weight gradients.  Every product ADDS into the gradient pool that the update's first node zeroed
+        # (beta = 1: split-K needs no memset node); the first layer's product (K0 wide) runs on the main stream,
+        # everything else beside it: the other layers' products, and ONE launch pair for all bias gradients and
+        # the head layer's weight gradient (weighted column sums).
+        with self._fork(0):
             prev = self.H[0]
             for i in range(1, M):
-                self._mm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, kscale=kscale)
-                self._colsum(self.Dl[i][0:2 * n], d.G('seq.%d.bias' % (3 * i)).view(1, -1), w=w_bias, part=part)
+                self._mm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0, kscale=kscale)
                 prev = self.H[i]
         with self._fork(1) as part:
-            self._colsum(self.H[M - 1], d.G('seq.%d.weight' % (3 * M)), w=w_last, part=part)
-            self._colsum(self.ones_col, d.G('seq.%d.bias' % (3 * M)).view(1, 1), w=w_last[0:2 * n], part=part)
-            self._colsum(self.Dl[0][0:2 * n], d.G('seq.0.bias').view(1, -1), w=w_bias, part=part)
-        if gram:
-            # penalty part (u^T diag(f c) u) W1 fills the gradient, the fake and real rows' product adds to it
-            u = self.Dl[0][gp_rows]
-            self._mm(u, u, self.P1, trans_a=True, kscale=pen_scale)
-            self._mm(self.P1, W1, d.G('seq.0.weight'))
-            ks2 = kscale[0:2 * n] if kscale is not None else None
+            probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
+            probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
+            probs.append((self.ones_col, w_last[0:2 * n], d.G('seq.%d.bias' % (3 * M))))
+            for i in range(0, len(probs), 8):
+                ops.colsum_multi(probs[i:i + 8], part)
             if self.sparse_d:
-                # data columns: product over the compact input into W1's layout; cond columns: sums of the
-                # (clip-scaled) delta rows by hot id, beside it, then transposed into place
-                with self._fork(1):
-                    self.dW1cT.zero_()
-                    ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT, rowscale=ks2)
+                # cond columns of dW1: sums of the (clip-scaled) delta rows by hot id, transposed into place below
+                ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
+                                 rowscale=kscale[0:2 * n] if kscale is not None else None)
+        if gram:
+            # penalty part (u^T diag(f c) u) W1, then the fake and real rows' product
+            u = self.Dl[0][gp_rows]
+            self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale)
+            self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0)
+            ks2 = kscale[0:2 * n] if kscale is not None else None
+            if self.sparse_d:       # data columns: product over the compact input into W1's layout
                 self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2,
                          seg_c=1, seg=self.seg)
             else:
                 self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2)
         else:
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
-            self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, kscale=kscale)
+            self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=kscale)
         self._join()
         if self.sparse_d:
             C, Dd, gw = self.C, self.Dd, d.G('seq.0.weight')
@@ -1037,8 +1087,8 @@ class StepEngine(object):
         # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
         # would take twice as long; from here on it runs beside that chain's small kernels
-        with self._fork(0) as part:
-            self._gen_dweight(c, L, self.dfake, part)
+        with self._fork(0):
+            self._gen_dweight(c, L, self.dfake)
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
@@ -1057,13 +1107,14 @@ class StepEngine(object):
                 self._mm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
             if l == 0:
                 # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
-                # bias gradient while the product runs beside it
-                with self._fork((L - l) % 2) as part:
-                    self._gen_dweight(c, l, self.dZ[l], part, what=1)
-                self._gen_dweight(c, l, self.dZ[l], self.part, what=2)
+                # bias gradients of every layer (one launch pair) while the product runs beside it
+                with self._fork((L - l) % 2):
+                    self._gen_dweight(c, l, self.dZ[l], what=1)
+                self._gen_dweight(c, l, self.dZ[l], what=2)
             else:
-                with self._fork((L - l) % 2) as part:           # after the chain's product, as above
-                    self._gen_dweight(c, l, self.dZ[l], part)
+                with self._fork((L - l) % 2):                   # after the chain's product, as above
+                    self._gen_dweight(c, l, self.dZ[l])
+        self._gen_bias_grads(self.part)
         self._join()
         if self.sparse_cond and not self.deterministic:
             # the scattered cond-column gradients into their places in the flat gradient buffer
@@ -1162,6 +1213,7 @@ class StepEngine(object):
             cv.copy_(cond)
             if self.sparse_cond:
                 ops.cond_to_sel(cv, c.sel)
+        self._gen_gx.zero_()            # the forward's BatchNorm accumulators live in the generator's zero pool
         self._gen_forward(c)
         out = torch.empty(self.B, self.Dd, device=self.dev)
         ops.apply_activate_fwd(c.fake, out, self.spans, rng=self.rng)

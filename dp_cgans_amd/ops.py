@@ -99,7 +99,7 @@ class GemmDesc(ctypes.Structure):
                 ('kscale', ctypes.c_void_p),
                 ('gat', ctypes.c_void_p), ('ldg', ctypes.c_int64), ('gidx', ctypes.c_void_p),
                 ('seg_b', ctypes.c_int32), ('seg_c', ctypes.c_int32), ('seg_len', ctypes.c_int32),
-                ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64)]
+                ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p)]
 
 
 def _addr(t):
@@ -135,7 +135,7 @@ def _mat_strides(t, trans):
 
 def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
               aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
-              seg_b=0, seg_c=0, seg=None):
+              seg_b=0, seg_c=0, seg=None, colstat=None):
     """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
     ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
     n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
@@ -174,6 +174,12 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     d.keep, d.ld_keep = _addr(keep), _ld(keep) if keep is not None else 0
     d.rng, d.site, d.splitk, d.tile, d.kscale = _addr(rng), site, int(splitk), int(tile), _addr(kscale)
     d.gat, d.ldg, d.gidx = _addr(gat), _ld(gat) if gat is not None else 0, _addr(gidx)
+    if colstat is not None:
+        _chk(colstat, torch.float64, 'colstat')
+        if colstat.numel() < 2 * N or not colstat.is_contiguous():
+            raise ValueError('gemm: colstat must be a contiguous fp64 [2, N]')
+        d.colstat = _addr(colstat)
+        d.splitk = 1
     if seg is not None:
         d.seg_b, d.seg_c = int(seg_b), int(seg_c)
         d.seg_len, d.seg_pad, d.seg_stride = int(seg[0]), int(seg[1]), int(seg[2])
@@ -204,10 +210,10 @@ def gemm(A, B, C, **kw):
     return C
 
 
-def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE, splitk=None):
+def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE, splitk=None, colstat=None):
     """C = epi(A @ op(B) + bias + gat[gidx[:,0]] + gat[gidx[:,1]]) (ids < 0 skipped): Linear over the dense
     columns of an input whose trailing cond columns are one-/two-hot; gat = W[:, cond columns]^T."""
-    gemm_run([gemm_desc(A, B, C, trans_b=trans_b, bias=bias, epi=epi, gat=gat, gidx=gidx, splitk=splitk)])
+    gemm_run([gemm_desc(A, B, C, trans_b=trans_b, bias=bias, epi=epi, gat=gat, gidx=gidx, splitk=splitk, colstat=colstat)])
     return C
 
 
@@ -407,10 +413,35 @@ def colreduce_partial(mode, x, part, w=None, y=None, z=None, mean=None, invstd=N
     return R.value
 
 
+def colreduce_rows(rows, F, max_R=64):
+    """Row chunks dpc_colreduce_partial uses for a [rows, F] matrix (pick_R of csrc/nets.hip)."""
+    R = min(-(-512 // -(-F // 64)), -(-rows // 64), max_R)
+    return max(R, 1)
+
+
 def colreduce_finish(part, R, nout, F, kind, out0, out1=None, count=1.0, eps=1e-5, momentum=0.1, run_mean=None,
                      run_var=None, accumulate=False):
     lib().call('dpc_colreduce_finish', _p(part), R, nout, F, kind, float(count), eps, momentum, _p(out0), _p(out1),
                _p(run_mean), _p(run_var), int(accumulate), _stream())
+
+
+def colsum_multi(problems, part, accumulate=False):
+    """problems: [(x [rows, F], w [rows] or None, out [F])], up to 8: out = sum_r w[r] x[r, :], two launches in all."""
+    n = len(problems)
+    for x, w, out in problems:
+        _chk(x, torch.float32, 'x')
+        _chk(w, torch.float32, 'w')
+        _chk(out, torch.float32, 'out')
+        if out.numel() != x.shape[1] or (w is not None and w.numel() != x.shape[0]):
+            raise ValueError('colsum_multi: out needs F entries, w one per row')
+    _chk(part, torch.float64, 'part')
+    P = ctypes.c_void_p * n
+    I64 = ctypes.c_int64 * n
+    I32 = ctypes.c_int * n
+    lib().call('dpc_colsum_multi', n, P(*[_addr(x) for x, _, _ in problems]), I64(*[_ld(x) for x, _, _ in problems]),
+               I64(*[x.shape[0] for x, _, _ in problems]), I32(*[x.shape[1] for x, _, _ in problems]),
+               P(*[_addr(w) for _, w, _ in problems]), P(*[_addr(o) for _, _, o in problems]), int(accumulate), _p(part),
+               part.numel(), _stream())
 
 
 def colsum_noalloc(x, out, w=None, accumulate=False):

@@ -83,7 +83,10 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
  *           pac-row layout [pac][Dd data | C cond] (seg_stride = Dd + C; dp_cgan.py:66-68, 622-623) in place:
  *           seg_b 1 = along K of a k-contiguous B (x W1^T; seg_pad % 32 == 0), seg_b 2 = along N of an
  *           n-contiguous B (dy W1; seg_pad % 4 == 0), seg_c 1 = along N of C (dy^T x accumulated into W1's
- *           layout, beta == 1; columns beyond seg_len of a segment are not stored). */
+ *           layout, beta == 1; columns beyond seg_len of a segment are not stored);
+ *   colstat (nullable, fp64 [2][N]) += column sums and column sums of squares of the result (epi 0, no
+ *           split-K): BatchNorm1d's batch statistics (dp_cgan.py:75-76) taken in the Linear's epilogue with
+ *           fp64 atomics; the caller zeroes it. */
 typedef struct dpc_gemm_desc {
   int32_t M, N, K;
   float alpha, beta;
@@ -101,6 +104,7 @@ typedef struct dpc_gemm_desc {
   const float* kscale;
   const float* gat; int64_t ldg; const int32_t* gidx;
   int32_t seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
+  double* colstat;
 } dpc_gemm_desc;
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */
@@ -268,6 +272,14 @@ int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int64_t rows, i
 int dpc_colreduce_finish(const double* part, int R, int nout, int F, int kind, double count, float eps,
                          float momentum, float* out0, float* out1, float* run_mean, float* run_var,
                          int accumulate, void* stream);
+/* n (<= 8) weighted column sums out_p[f] (+)= sum_r w_p[r] * x_p[r*ldx_p + f] in two launches for all of them:
+ * the bias gradients and the head layer's weight gradient of one backward pass (autograd of the Linear
+ * layers, dp_cgan.py:40,43,75,95).  All array arguments are HOST arrays of n entries, w[p] nullable; part:
+ * fp64 workspace of part_cap >= 64 * sum(F) elements.  Bit-identical to dpc_colreduce_partial(mode 1) +
+ * dpc_colreduce_finish(kind 1) per sum. */
+int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
+                     const float* const* w, float* const* out, int accumulate, double* part, int64_t part_cap,
+                     void* stream);
 /* out[f] (+)= sum_r w[r] * x[r*ldx + f] (w nullable = all ones): dpc_colreduce_partial(mode 1, max_R 64) +
  * dpc_colreduce_finish(kind 1) in one call that ALLOCATES NOTHING and takes no workspace: the row-chunk
  * partial sums live in a 4 MiB file-scope device array of the library (one copy per GPU, held until the
