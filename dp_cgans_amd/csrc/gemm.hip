@@ -481,6 +481,119 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, split == 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small products (few 64x64 tiles, short K: the K = 256 links of the discriminator's chains at batch 1024-3072)
+// are bound by a block's serial walk over K, not by the matrix cores: with 64-192 blocks on 256 CUs a block
+// pays a load round trip + 16 MFMAs per K-tile, tile after tile.  Here a block owns a 32 x 32 tile of C (4 x as
+// many blocks) and its 4 waves SPLIT K: a group of 8 K-tiles (256 k) is loaded at once - every load of the
+// group in flight together - wave w takes tiles w and w + 4 of the group, and the four partial accumulators
+// meet in LDS, where 256 threads x 4 consecutive columns apply the epilogue with 16-byte accesses.
+// K = 256 is one round trip and 32 MFMAs per wave instead of eight of each.
+// ---------------------------------------------------------------------------------------------
+constexpr int KS_GROUP = 8;          // K-tiles per group (2 per wave)
+
+template <bool A_KC, bool B_KC, bool KS>
+__global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
+  using SA = Stage<32, A_KC, KS>;
+  using SB = Stage<32, B_KC>;
+  static_assert(SA::SIZE == SB::SIZE, "32 x 32 tiles: both images are 32 x 36 floats");
+  constexpr int TS = SA::SIZE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * KS_GROUP * TS];        // A tiles, then B tiles (72 KB)
+  float* As = lds;
+  float* Bs = lds + KS_GROUP * TS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  int tile_m, tile_n;
+  gemm_tile_coords(g, gemm_xcd_slot(blockIdx.x, g.tiles_m * g.tiles_n), tile_m, tile_n);
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+  const int64_t lda = A_KC ? g.a_rs : g.a_cs;
+  const int64_t ldb = B_KC ? g.b_cs : g.b_rs;
+  const bool fa = g.a_vec && (A_KC ? true : (m0 + 32 <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
+  const bool fb = g.b_vec && (B_KC ? true : (n0 + 32 <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  SA sa[KS_GROUP];
+  SB sb[KS_GROUP];
+  const int ntile = (g.K + BK - 1) / BK;
+  for (int t0 = 0; t0 < ntile; t0 += KS_GROUP) {
+#pragma unroll
+    for (int j = 0; j < KS_GROUP; ++j) {
+      const int k0 = min(t0 + j, ntile - 1) * BK;          // (tiles past the end re-load the last one and are not used)
+      sa[j].load(g.A, lda, m0, k0, g.M, g.K, fa, g.kscale);
+      sb[j].load(g.B, ldb, n0, k0, g.N, g.K, fb);
+    }
+    if (t0 > 0) __syncthreads();                           // the previous group's LDS reads are done
+#pragma unroll
+    for (int j = 0; j < KS_GROUP; ++j) {
+      sa[j].store(As + j * TS);
+      sb[j].store(Bs + j * TS);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < KS_GROUP / 4; ++h) {
+      const int j = wave + 4 * h;
+      if (t0 + j < ntile) {
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+          float a[4], b[4];
+          SA::frag(As + j * TS, 0, kb, li, lk, a);
+          SB::frag(Bs + j * TS, 0, kb, li, lk, b);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // the four waves' partial tiles meet in LDS: red[wave][row][col], rows of 32 floats
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc[e];
+  __syncthreads();
+  const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  const int row = m0 + r;
+  if (row >= g.M) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(&red[r * 32 + c4]);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&red[w * 1024 + r * 32 + c4]);
+  float out[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = n0 + c4 + q;
+    if (col >= g.N) continue;
+    float x = g.alpha * out[q] + (g.bias ? g.bias[col] : 0.f);
+    float* cp = g.C + (int64_t)row * g.ldc + col;
+    if (g.epi == EPI_LEAKY_DROPOUT) {
+      float keep;
+      if (g.keep) keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+      else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
+      const float slope = (x > 0.f ? 1.f : g.leak) * keep * 2.f;
+      g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+      x *= slope;
+    } else if (g.epi == EPI_MUL) {
+      x *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+    } else if (g.epi == EPI_RELU) {
+      x = fmaxf(x, 0.f);
+    }
+    if (g.beta != 0.f) x += g.beta * (*cp);
+    *cp = x;
+  }
+}
+
+static void launch_ksplit(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
+  dim3 grid(g.tiles_m * g.tiles_n), block(256);
+  if (g.kscale) {
+    if (b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, true>), grid, block, 0, st, g);
+    return;
+  }
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, true, false>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, false, false>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, false>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, false>), grid, block, 0, st, g);
+}
+
 // Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
 __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
   int64_t total = (int64_t)g.M * g.N;
@@ -534,7 +647,7 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   DPC_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_RELU, "gemm: unknown epilogue");
   DPC_CHECK_ARG(epi != EPI_LEAKY_DROPOUT || (d.aux_out && (d.keep || d.rng)), "gemm: dropout epilogue needs slope output and a mask source");
   DPC_CHECK_ARG(epi != EPI_MUL || d.aux_in, "gemm: multiply epilogue needs aux_in");
-  DPC_CHECK_ARG(d.tile == 0 || d.tile == 64 || d.tile == 128, "gemm: tile must be 0 (automatic), 64 or 128");
+  DPC_CHECK_ARG(d.tile == 0 || d.tile == 32 || d.tile == 64 || d.tile == 128, "gemm: tile must be 0 (automatic), 32, 64 or 128");
   GemmArgs g;
   g.A = d.A; g.a_rs = d.a_rs; g.a_cs = d.a_cs;
   g.B = d.B; g.b_rs = d.b_rs; g.b_cs = d.b_cs;
@@ -580,6 +693,19 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   // blocks fill the 256 CUs.
   int bm = 64, bn = 64;
   if (d.tile == 128 || (d.tile == 0 && dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512)) { bm = 128; bn = 128; }
+  // small product (fewer 64x64 tiles than CUs, short K): 32x32 tiles whose waves split K (gemm_ksplit_kernel)
+  const bool plain = !d.gat && !d.colstat && !d.seg_b && !d.seg_c;
+  if (d.tile == 32 || (d.tile == 0 && plain && d.splitk <= 1 && K <= 1024 && K >= 64 &&
+                       dpc_cdiv(M, 64) * dpc_cdiv(N, 64) < 256 && dpc_cdiv(M, 32) * dpc_cdiv(N, 32) >= 64 &&
+                       dpc_cdiv(M, 32) * dpc_cdiv(N, 32) <= 512)) {      // (72 KB of LDS: two blocks per CU, one round)
+    DPC_CHECK_ARG(plain && d.splitk <= 1, "gemm: the 32x32 K-split tile takes no row gather, column statistics, segment map or split-K");
+    g.tiles_m = (int)dpc_cdiv(M, 32);
+    g.tiles_n = (int)dpc_cdiv(N, 32);
+    g.splitk = 1; g.kchunk = K;
+    launch_ksplit(g, a_kc, b_kc, st);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+  }
   g.tiles_m = (int)dpc_cdiv(M, bm);
   g.tiles_n = (int)dpc_cdiv(N, bn);
   const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;

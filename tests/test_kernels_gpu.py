@@ -107,6 +107,50 @@ def test_gemm_epilogues(ops):
     close(H, (X.double() @ W.double().t()) * Mul.double(), what='mul epilogue')
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 256, 256), (3072, 256, 256), (256, 256, 1024), (130, 77, 201), (33, 31, 64), (500, 96, 1000)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
+def test_gemm_small_product_kernel_whose_waves_split_k(ops, M, N, K, ta, tb):
+    """tile=32 (gemm_ksplit_kernel: 32x32 tiles, the block's four waves split K): every layout, the shapes of
+    the discriminator's K = 256 chain links, ragged edges, each epilogue, beta, and the clip scale of the
+    weight-gradient layout - against fp64."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    d_ = dev()
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    prod = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    Ad, Bd = A.to(d_), B.to(d_)
+    C = torch.full((M, N), float('nan'), device=d_)
+    ops.gemm(Ad, Bd, C, trans_a=ta, trans_b=tb, tile=32)
+    close(C, prod, what='plain')
+    C64 = torch.empty(M, N, device=d_)
+    ops.gemm(Ad, Bd, C64, trans_a=ta, trans_b=tb, tile=64, splitk=1)
+    close(C, C64, what='vs the 64x64 tile', rtol=2e-6)
+    bias = torch.randn(N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    C.copy_(base)
+    ops.gemm(Ad, Bd, C, trans_a=ta, trans_b=tb, tile=32, bias=bias.to(d_), alpha=0.5, beta=2.0)
+    close(C, 0.5 * prod + bias.double() + 2.0 * base.double(), what='bias, alpha, beta')
+    mul = torch.randn(M, N, generator=g)
+    ops.gemm(Ad, Bd, C, trans_a=ta, trans_b=tb, tile=32, epi=ops.EPI_MUL, aux_in=mul.to(d_))
+    close(C, prod * mul.double(), what='multiply epilogue')
+    ops.gemm(Ad, Bd, C, trans_a=ta, trans_b=tb, tile=32, epi=ops.EPI_RELU, bias=bias.to(d_))
+    close(C, torch.relu(prod + bias.double()), what='ReLU epilogue')
+    rng = ops.new_rng(99, d_)
+    kb = torch.empty(M, N, dtype=torch.uint8, device=d_)
+    ops.fill(kb, ops.FILL_KEEP, rng, 21)
+    S = torch.empty(M, N, device=d_)
+    ops.gemm(Ad, Bd, C, trans_a=ta, trans_b=tb, tile=32, bias=bias.to(d_), epi=ops.EPI_LEAKY_DROPOUT, aux_out=S, rng=rng, site=21)
+    pre = prod + bias.double()
+    slope = torch.where(pre > 0, 1.0, 0.2) * kb.cpu().double() * 2
+    ok = pre.abs() > 1e-5 * float(pre.abs().max())                # (a pre-activation within rounding of 0 may take either slope)
+    close(torch.where(ok.to(d_), S, 0.0), torch.where(ok, slope, 0.0), what='slopes from the Philox keep bits')
+    close(torch.where(ok.to(d_), C, 0.0), torch.where(ok, pre * slope, 0.0), what='LeakyReLU + Dropout epilogue')
+    if ta:
+        ks = torch.rand(K, generator=g)
+        ops.gemm(Ad, Bd, C, trans_a=True, trans_b=tb, tile=32, kscale=ks.to(d_))
+        close(C, (A * ks[:, None]).t().double() @ (B.t() if tb else B).double(), what='clip scale')
+
+
 @pytest.mark.parametrize('n,pac,Dd,C,d0', [(64, 8, 335, 276, 256), (10, 10, 56, 38, 128), (37, 3, 40, 30, 21), (1024, 8, 335, 276, 256)])
 def test_gemm_segment_maps_run_over_the_data_columns_of_the_pac_row_layout(ops, n, pac, Dd, C, d0):
     """The three products of the discriminator's first layer over the DATA columns of its pac-row input
