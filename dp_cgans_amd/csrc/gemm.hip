@@ -490,9 +490,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // meet in LDS, where 256 threads x 4 consecutive columns apply the epilogue with 16-byte accesses.
 // K = 256 is one round trip and 32 MFMAs per wave instead of eight of each.
 // ---------------------------------------------------------------------------------------------
-constexpr int KS_GROUP = 8;          // K-tiles per group (2 per wave)
-
-template <bool A_KC, bool B_KC, bool KS>
+// KS_GROUP: K-tiles per group, 8 (2 per wave, 72 KB of LDS: two blocks per CU) or 4 (36 KB: four per CU)
+template <bool A_KC, bool B_KC, bool KS, int KS_GROUP>
 __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
   using SA = Stage<32, A_KC, KS>;
   using SB = Stage<32, B_KC>;
@@ -581,17 +580,18 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
   }
 }
 
+template <int GRP>
 static void launch_ksplit(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n), block(256);
   if (g.kscale) {
-    if (b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, true>), grid, block, 0, st, g);
+    if (b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, true, GRP>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, true, GRP>), grid, block, 0, st, g);
     return;
   }
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, true, false>), grid, block, 0, st, g);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, false, false>), grid, block, 0, st, g);
-  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, false>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, false>), grid, block, 0, st, g);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, true, false, GRP>), grid, block, 0, st, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<true, false, false, GRP>), grid, block, 0, st, g);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_ksplit_kernel<false, true, false, GRP>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_ksplit_kernel<false, false, false, GRP>), grid, block, 0, st, g);
 }
 
 // Bias + activation pass over C for products that ran split-K (the atomics carry the plain sums).
@@ -647,7 +647,7 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   DPC_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_RELU, "gemm: unknown epilogue");
   DPC_CHECK_ARG(epi != EPI_LEAKY_DROPOUT || (d.aux_out && (d.keep || d.rng)), "gemm: dropout epilogue needs slope output and a mask source");
   DPC_CHECK_ARG(epi != EPI_MUL || d.aux_in, "gemm: multiply epilogue needs aux_in");
-  DPC_CHECK_ARG(d.tile == 0 || d.tile == 32 || d.tile == 64 || d.tile == 128, "gemm: tile must be 0 (automatic), 32, 64 or 128");
+  DPC_CHECK_ARG(d.tile == 0 || d.tile == 32 || d.tile == 324 || d.tile == 64 || d.tile == 128, "gemm: tile must be 0 (automatic), 32, 64 or 128");
   GemmArgs g;
   g.A = d.A; g.a_rs = d.a_rs; g.a_cs = d.a_cs;
   g.B = d.B; g.b_rs = d.b_rs; g.b_cs = d.b_cs;
@@ -695,14 +695,15 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   if (d.tile == 128 || (d.tile == 0 && dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512)) { bm = 128; bn = 128; }
   // small product (fewer 64x64 tiles than CUs, short K): 32x32 tiles whose waves split K (gemm_ksplit_kernel)
   const bool plain = !d.gat && !d.colstat && !d.seg_b && !d.seg_c;
-  if (d.tile == 32 || (d.tile == 0 && plain && d.splitk <= 1 && K <= 1024 && K >= 64 &&
-                       dpc_cdiv(M, 64) * dpc_cdiv(N, 64) < 256 && dpc_cdiv(M, 32) * dpc_cdiv(N, 32) >= 64 &&
-                       dpc_cdiv(M, 32) * dpc_cdiv(N, 32) <= 512)) {      // (72 KB of LDS: two blocks per CU, one round)
+  if (d.tile == 32 || d.tile == 324 || (d.tile == 0 && plain && d.splitk <= 1 && K <= 1024 && K >= 64 &&
+                       dpc_cdiv(M, 64) * dpc_cdiv(N, 64) < 256 && dpc_cdiv(M, 32) * dpc_cdiv(N, 32) >= 64)) {
     DPC_CHECK_ARG(plain && d.splitk <= 1, "gemm: the 32x32 K-split tile takes no row gather, column statistics, segment map or split-K");
     g.tiles_m = (int)dpc_cdiv(M, 32);
     g.tiles_n = (int)dpc_cdiv(N, 32);
     g.splitk = 1; g.kchunk = K;
-    launch_ksplit(g, a_kc, b_kc, st);
+    // up to two blocks per CU: groups of 8 K-tiles (72 KB of LDS); more: groups of 4 (36 KB, four blocks per CU)
+    if ((int64_t)g.tiles_m * g.tiles_n > 512 || d.tile == 324) launch_ksplit<4>(g, a_kc, b_kc, st);
+    else launch_ksplit<8>(g, a_kc, b_kc, st);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
   }

@@ -76,7 +76,7 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
  * be library state and the segment maps.  Zero-fill it, then set what the product needs.
  *   splitk  0 automatic, 1 never (no fp32 atomics: bit-reproducible results), n > 1 forced;
  *   tile    0 automatic, 64 (64x64 block tile), 128 (128x128) or 32 (32x32 tiles whose four waves split K:
- *           the small-product kernel);
+ *           the small-product kernel; 324 = the same with groups of 4 K-tiles);
  *   gat / ldg / gidx  the row gather of dpc_gemm_f32_gather;
  *   seg_*   segment map: index x of a compact axis made of segments of seg_pad entries addresses element
  *           (x / seg_pad) * seg_stride + x % seg_pad of the stored axis, the first seg_len entries of a

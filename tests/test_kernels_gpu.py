@@ -125,6 +125,8 @@ def test_gemm_small_product_kernel_whose_waves_split_k(ops, M, N, K, ta, tb):
     C64 = torch.empty(M, N, device=d_)
     ops.gemm(Ad, Bd, C64, trans_a=ta, trans_b=tb, tile=64, splitk=1)
     close(C, C64, what='vs the 64x64 tile', rtol=2e-6)
+    ops.gemm(Ad, Bd, C64, trans_a=ta, trans_b=tb, tile=324)
+    close(C64, prod, what='groups of 4 K-tiles')
     bias = torch.randn(N, generator=g)
     base = torch.randn(M, N, generator=g)
     C.copy_(base)
