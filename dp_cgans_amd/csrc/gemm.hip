@@ -64,6 +64,7 @@ struct GemmArgs {
   // with fp64 atomics - BatchNorm1d's batch statistics taken where the Linear's output tile still sits in
   // registers (dp_cgan.py:75-76).  fp32 sums over the 32 rows of an MFMA tile, fp64 across tiles.
   double* colstat;
+  int force_atomic;      // add the result to C with fp32 atomics even without split-K (another product adds to C meanwhile)
 };
 
 // stored index minus compact index
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   int k_begin = split * g.kchunk;
   int k_end = min(g.K, k_begin + g.kchunk);
   if (k_begin >= k_end && split > 0) return;
-  gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1, split == 0);
+  gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1 || g.force_atomic, split == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -666,6 +667,9 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   // segment maps (GemmArgs::seg_*)
   g.seg_b = d.seg_b; g.seg_c = d.seg_c; g.seg_len = d.seg_len; g.seg_pad = d.seg_pad; g.seg_stride = d.seg_stride;
   g.colstat = d.colstat;
+  g.force_atomic = d.atomic ? 1 : 0;
+  DPC_CHECK_ARG(!d.atomic || (beta == 1.f && epi == EPI_NONE && !d.bias && !d.gat && !d.colstat && d.tile != 32 && d.tile != 324),
+                "gemm: atomic accumulation needs beta == 1 and a plain product");
   DPC_CHECK_ARG(!d.colstat || (epi == EPI_NONE && !d.seg_c && (d.splitk == 0 || d.splitk == 1)),
                 "gemm: column statistics go with epilogue none, a plain C and no split-K");
   if (d.seg_b || d.seg_c) {
@@ -694,7 +698,7 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   int bm = 64, bn = 64;
   if (d.tile == 128 || (d.tile == 0 && dpc_cdiv(M, 128) * dpc_cdiv(N, 128) >= 512)) { bm = 128; bn = 128; }
   // small product (fewer 64x64 tiles than CUs, short K): 32x32 tiles whose waves split K (gemm_ksplit_kernel)
-  const bool plain = !d.gat && !d.colstat && !d.seg_b && !d.seg_c;
+  const bool plain = !d.gat && !d.colstat && !d.seg_b && !d.seg_c && !d.atomic;
   if (d.tile == 32 || d.tile == 324 || (d.tile == 0 && plain && d.splitk <= 1 && K <= 1024 && K >= 64 &&
                        dpc_cdiv(M, 64) * dpc_cdiv(N, 64) < 256 && dpc_cdiv(M, 32) * dpc_cdiv(N, 32) >= 64)) {
     DPC_CHECK_ARG(plain && d.splitk <= 1, "gemm: the 32x32 K-split tile takes no row gather, column statistics, segment map or split-K");

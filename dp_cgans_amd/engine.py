@@ -981,11 +981,15 @@ class StepEngine(object):
                 ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
                                  rowscale=kscale[0:2 * n] if kscale is not None else None)
         if gram:
-            # penalty part (u^T diag(f c) u) W1, then the fake and real rows' product
+            # penalty part (u^T diag(f c) u) W1 beside the fake and real rows' product: both ADD into the zeroed
+            # gradient (the penalty part with atomics too - the two run at the same time)
             u = self.Dl[0][gp_rows]
-            self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale)
-            self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0)
+            with self._fork(0):
+                self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale)
+                self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0, atomic=not self.deterministic)
             ks2 = kscale[0:2 * n] if kscale is not None else None
+            if self.deterministic:
+                self._join()
             if self.sparse_d:       # data columns: product over the compact input into W1's layout
                 self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2,
                          seg_c=1, seg=self.seg)

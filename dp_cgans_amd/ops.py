@@ -99,7 +99,8 @@ class GemmDesc(ctypes.Structure):
                 ('kscale', ctypes.c_void_p),
                 ('gat', ctypes.c_void_p), ('ldg', ctypes.c_int64), ('gidx', ctypes.c_void_p),
                 ('seg_b', ctypes.c_int32), ('seg_c', ctypes.c_int32), ('seg_len', ctypes.c_int32),
-                ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p)]
+                ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p),
+                ('atomic', ctypes.c_int32)]
 
 
 def _addr(t):
@@ -135,7 +136,7 @@ def _mat_strides(t, trans):
 
 def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
               aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
-              seg_b=0, seg_c=0, seg=None, colstat=None):
+              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False):
     """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
     ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
     n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
@@ -174,6 +175,7 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     d.keep, d.ld_keep = _addr(keep), _ld(keep) if keep is not None else 0
     d.rng, d.site, d.splitk, d.tile, d.kscale = _addr(rng), site, int(splitk), int(tile), _addr(kscale)
     d.gat, d.ldg, d.gidx = _addr(gat), _ld(gat) if gat is not None else 0, _addr(gidx)
+    d.atomic = 1 if atomic else 0
     if colstat is not None:
         _chk(colstat, torch.float64, 'colstat')
         if colstat.numel() < 2 * N or not colstat.is_contiguous():

@@ -87,7 +87,9 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
  *           layout, beta == 1; columns beyond seg_len of a segment are not stored);
  *   colstat (nullable, fp64 [2][N]) += column sums and column sums of squares of the result (epi 0, no
  *           split-K): BatchNorm1d's batch statistics (dp_cgan.py:75-76) taken in the Linear's epilogue with
- *           fp64 atomics; the caller zeroes it. */
+ *           fp64 atomics; the caller zeroes it;
+ *   atomic  != 0: the product is ADDED to C with fp32 atomics whether or not K is split (beta == 1, plain
+ *           product): for products that accumulate into one C concurrently on different streams. */
 typedef struct dpc_gemm_desc {
   int32_t M, N, K;
   float alpha, beta;
@@ -106,6 +108,7 @@ typedef struct dpc_gemm_desc {
   const float* gat; int64_t ldg; const int32_t* gidx;
   int32_t seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
   double* colstat;
+  int32_t atomic;
 } dpc_gemm_desc;
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */
