@@ -990,11 +990,13 @@ class StepEngine(object):
             ks2 = kscale[0:2 * n] if kscale is not None else None
             if self.deterministic:
                 self._join()
+            at = not self.deterministic      # (both products add to the same gradient at the same time: atomics on both sides)
             if self.sparse_d:       # data columns: product over the compact input into W1's layout
                 self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2,
-                         seg_c=1, seg=self.seg)
+                         seg_c=1, seg=self.seg, atomic=at)
             else:
-                self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2)
+                self._mm(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=ks2,
+                         atomic=at)
         else:
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
             self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=kscale)

@@ -46,7 +46,8 @@ class AdamAwareCompare(object):
         self.loose, self.steps, self.lr = {}, 0, lr
 
     def check(self, key, mine, ref_p, ref_g, what):
-        tiny = np.abs(ref_g) < 1e-5 * max(np.abs(ref_g).max(), 1e-30)
+        # (exact zeros - e.g. cond columns no row of the batch selected - are NOT excused: both sides must leave them alone)
+        tiny = (np.abs(ref_g) < 1e-5 * max(np.abs(ref_g).max(), 1e-30)) & (ref_g != 0)
         self.loose[key] = tiny | self.loose.get(key, np.zeros_like(tiny))
         lo = self.loose[key]
         mine = mine.detach().cpu().numpy()
@@ -54,7 +55,9 @@ class AdamAwareCompare(object):
         err = np.abs(mine - ref_p)
         assert (err[~lo] / sc).max(initial=0.0) <= RTOL, '%s: %.3e' % (what, (err[~lo] / sc).max())
         assert err[lo].max(initial=0.0) <= self.lr * self.steps, '%s (noise-sized grads): %.3e' % (what, err[lo].max())
-        assert lo.size < 64 or lo.mean() < 0.5, '%s: too many entries excused (%.2f)' % (what, lo.mean())
+        # what the excuse covers is reported and capped: at most a tenth of a tensor's entries
+        self.worst = max(getattr(self, 'worst', 0.0), float(lo.mean()) if lo.size >= 64 else 0.0)
+        assert lo.size < 64 or lo.mean() <= 0.1, '%s: too many entries excused (%.3f)' % (what, lo.mean())
 
 
 def make_engine(tr, device='cuda:0'):
@@ -145,6 +148,8 @@ def test_engine_replays_reference_training_steps(name):
                     assert np.abs(eng.gen.P(k).cpu().numpy() - ref_p[k]).max() < 2e-4 * cmp_g.steps
                 else:
                     cmp_g.check(k, eng.gen.P(k), ref_p[k], ref_g[k], 's%d G param %s' % (s, k))
+    print('%s: largest excused fraction of a tensor (noise-sized gradients): D %.4f, G %.4f'
+          % (name, getattr(cmp_d, 'worst', 0.0), getattr(cmp_g, 'worst', 0.0)))
     sd = eng.generator_state_dict()
     for k in tr.z.files:
         if k.startswith('gen_final/') and 'running' in k:
@@ -458,3 +463,76 @@ def test_dpsgd_against_oracle_on_odd_shapes(cfg):
     assert float(eng.rowc.min()) < 1.0 and float(eng.rowc.max()) == 1.0
     for k in eng.disc.keys:
         close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='clipped mean grad ' + k)
+
+
+def test_dpsgd_graph_replayed_training_steps_match_the_oracle_chain():
+    """Two full Philox-driven DP-SGD training steps (discriminator update with per-example clipping and Gaussian
+    noise, then generator update) replayed through GraphStep, against the oracle chain oracle/dpsgd.py +
+    oracle/nets.py run on the SAME draws: z, Gumbel noise, Dropout bits, alpha and the DP noise are read back
+    through dpc_fill's index map (call sites offset by 64 per update, one Philox step per training step), the
+    sampled cond vectors / permutation / real rows from the engine's buffers.  Parameters after every step."""
+    from golden_util import load
+    from dp_cgans_amd import ops
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    from oracle import dpsgd
+    from oracle import nets as onets
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+    E, B, pac, sigma, clip = 24, 120, 10, 0.7, 0.02
+    eng = StepEngine(span, E, (40, 24), (48, 16), B, pac, dev, private=True, dp_mode='dpsgd', dp_sigma=sigma, dp_clip=clip,
+                     seed=21)
+    eng.sampler = DataSampler(enc, span, device=dev, seed=4)
+    n, Dd = eng.n, eng.Dd
+    gp = {k: v.cpu() for k, v in eng.gen.state_dict().items()}
+    dp = {k: v.cpu() for k, v in eng.disc.state_dict().items()}
+    sd, sg = {'t': 0, 'm': {}, 'v': {}}, {'t': 0, 'm': {}, 'v': {}}
+    seed, seed_shared = int(eng.rng[0]), int(eng.rng_shared[0])
+    gs = GraphStep(eng, d_steps=1)
+    cmp_d, cmp_g = AdamAwareCompare(), AdamAwareCompare()
+
+    def draws(step, k, rows):
+        rng = torch.tensor([seed, step], dtype=torch.int64, device=dev)
+        so = 64 * k
+        e = torch.empty(B, Dd, device=dev)
+        ops.fill(e, ops.FILL_EXP, rng, ops.SITE_GUMBEL + so)
+        zz = torch.empty(B, E, device=dev)
+        ops.fill(zz, ops.FILL_NORMAL, rng, ops.SITE_Z + so)
+        keeps = []
+        for i, w in enumerate(eng.ddim):
+            kb = torch.empty(rows, w, dtype=torch.uint8, device=dev)
+            ops.fill(kb, ops.FILL_KEEP, rng, ops.SITE_DROP0 + i + so)
+            keeps.append(kb.cpu())
+        al = torch.empty(n, device=dev)
+        ops.fill(al, ops.FILL_UNIFORM, rng, ops.SITE_ALPHA + so)
+        return e.cpu(), zz.cpu(), keeps, al.cpu()
+
+    for step in range(3):                # eager, capture, replay
+        gs.run()
+        torch.cuda.synchronize()
+        # ---- discriminator update (update 0 of the step)
+        e, zz, keeps, al = draws(step, 0, 3 * n)
+        cond, perm, real = eng.cd.cond.cpu(), eng.perm.cpu(), eng.Xd[B:2 * B, :Dd].cpu()
+        mk = lambda g_: [k[g_ * n:(g_ + 1) * n] for k in keeps]
+        out = dpsgd.d_step_grads_dpsgd(gp, dp, span, pac, zz, cond, perm, real, e, mk(0), mk(1), mk(2), al, clip=clip)
+        flat = torch.empty(eng.disc.n, device=dev)
+        ops.fill(flat, ops.FILL_NORMAL, torch.tensor([seed_shared, step], dtype=torch.int64, device=dev), ops.SITE_NOISE_D)
+        flat = flat.cpu()
+        per = {k: flat[eng.disc.offsets[k]:eng.disc.offsets[k] + dp[k].numel()].view(dp[k].shape) for k in eng.disc.keys}
+        noisy = dpsgd.add_noise(out['grads'], per, sigma, clip, n)
+        dp = onets.apply_update(dp, noisy, sd)
+        cmp_d.steps += 1
+        for k in eng.disc.keys:
+            cmp_d.check(k, eng.disc.P(k), dp[k].numpy(), noisy[k].numpy(), 'step %d D param %s' % (step, k))
+        # ---- generator update (update 1 of the step)
+        e, zz, keeps, al = draws(step, 1, n)
+        outg = onets.g_step_grads(gp, dp, span, pac, zz, eng.cg.cond.cpu(), eng.cg.mask.cpu(), e, keeps)
+        gp = onets.apply_update(gp, outg['grads'], sg)
+        cmp_g.steps += 1
+        for k in eng.gen.keys:
+            if 'fc.bias' in k:      # exactly-zero gradient in front of BatchNorm: Adam turns rounding noise into +-lr steps
+                assert np.abs(eng.gen.P(k).cpu().numpy() - gp[k].numpy()).max() < 2e-4 * cmp_g.steps
+            else:
+                cmp_g.check(k, eng.gen.P(k), gp[k].numpy(), outg['grads'][k].numpy(), 'step %d G param %s' % (step, k))
+    assert len(gs.items) == 1 and int(eng.disc.t) == 3 and int(eng.gen.t) == 3
