@@ -44,7 +44,6 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from dp_cgans_amd import ops
     from dp_cgans_amd.data_sampler import DataSampler
     from dp_cgans_amd.engine import GraphStep, StepEngine
     from dp_cgans_amd.parallel import Dist
@@ -99,107 +98,21 @@ def main():
                                   else 'reference hook-noise + weight clamp', args.d_steps,
                                   {'T1M': 2, 'T10M': 3, 'TWIDE': 4}.get(args.table, 2)),
                    'global_batch': args.batch * dist.world, 'parallelism': 'dp%d' % dist.world,
-                   'launch': 'eager' if args.no_graph else 'hipGraph replay (%d segment(s))' % len(gstep.items or []),
-                   'data_dim': eng.Dd, 'cond_dim': eng.C, 'n_discrete': eng.nd, 'setup_s': round(setup_s, 2),
+                   'launch': 'eager' if args.no_graph else 'hipGraph replay (%d graph segment(s)%s)' % (
+                       sum(1 for k, _ in (gstep.items or []) if k == 'graph'),
+                       '' if not dist.active else (', RCCL all-reduces captured in the graph' if gstep.collectives_in_graph
+                                                   else ', %d eager all-reduces between them' % sum(1 for k, _ in gstep.items if k != 'graph'))),
+                   'data_dim': eng.Dd, 'cond_dim': eng.C, 'n_discrete': eng.nd, 'batch': args.batch, 'pac': args.pac,
+                   'gen_dims': list(dims), 'disc_dims': list(dims), 'embedding_dim': eng.E,
+                   'k0_compact': getattr(eng, 'K0x', eng.K0), 'disc_params': eng.disc.n, 'gen_params': eng.gen.n,
+                   'setup_s': round(setup_s, 2),
                    'final_losses': [round(x, 5) for x in losses]},
     }
 
     if dist.rank == 0 and not args.no_roofline:
-        # Live per-launch timing of the dominant kernel (gemm_f32_kernel, all tile variants): HIP
-        # events on the launch stream around every GEMM of a further `steps` training steps.
-        ops.GEMM_PROFILE = []
-        nprof = min(args.steps, 20)
         if dist.world == 1:
-            eng.concurrent = False       # one stream: every GEMM's events bracket that GEMM alone
-            for _ in range(nprof):
-                eager_step()
-            torch.cuda.synchronize()
-            eng.concurrent = True
-            prof = ops.GEMM_PROFILE
-            ops.GEMM_PROFILE = None
-            if os.environ.get('DPC_GEMM_BREAKDOWN'):      # per-shape launch times of one step, to stderr
-                per = {}
-                for i, (e0, e1, f, shp, _) in enumerate(prof):
-                    per.setdefault((i % (len(prof) // nprof), shp), []).append(e0.elapsed_time(e1) * 1e3)
-                for (i, shp), v in sorted(per.items()):
-                    us = sum(v) / len(v)
-                    sys.stderr.write('%2d M=%5d N=%5d K=%5d ta=%d tb=%d  %7.1f us %6.1f TF/s\n'
-                                     % (i, shp[0], shp[1], shp[2], shp[3], shp[4], us, 2e-6 * shp[0] * shp[1] * shp[2] / us))
-            ms_each = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in prof)     # every launch bracketed on its own
-            flops = sum(f for _, _, f, _, _ in prof)
-            alg_bytes = sum(4.0 * (m * k + k * n + m * n) for _, _, _, (m, n, k, _, _), _ in prof) / len(prof)
-            # The dominant kernel's launches of ONE step issued again back to back (identical arguments and
-            # buffers) between two events: the per-launch figure above also counts the stream's idle time
-            # between an event record and the launch it brackets (a few us each on an eager stream), this one
-            # is kernel time (memset / deferred epilogue of a split product included), which is what the
-            # rocprofv3 kernel trace of the same command reports.
-            per_step = len(prof) // nprof
-            calls = [c for _, _, _, _, c in prof[:per_step]]
-            reps = 20
-            for c in calls:
-                c()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                for c in calls:
-                    c()
-            e1.record()
-            torch.cuda.synchronize()
-            eng.Zp.zero_()               # the replayed first-layer products added into it
-            ms = e0.elapsed_time(e1) / reps * nprof
-            achieved = flops / (ms * 1e-3) / 1e12
-            # HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of this workload
-            # (tools/pmc_traffic.py, gfx950 correction applied); only valid for the default workload
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')
-            default_wl = (args.table == 'T1M' and args.rows is None and args.batch == 8192 and args.pac == 8
-                          and args.dims == '256,256' and args.d_steps == 1 and args.dp_mode == 'dpsgd')
-            if default_wl and os.path.exists(tpath):
-                traffic = json.load(open(tpath))['traffic_bytes_per_launch']
-            out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC passes)',
-                               'algorithmic_bytes_per_launch': alg_bytes,
-                               'kernel': 'gemm_f32_kernel', 'launches_per_step': len(prof) / nprof,
-                               'gflop_per_launch': flops / len(prof) / 1e9,
-                               'avg_launch_us': 1e3 * ms / len(prof),
-                               'gflop_per_step': flops / nprof / 1e9, 'gemm_ms_per_step': ms / nprof,
-                               'avg_launch_us_bracketed_singly': 1e3 * ms_each / len(prof),
-                               'method': 'one step\'s GEMM launches replayed back to back, %d repetitions, HIP events' % reps}
-        ops.GEMM_PROFILE = None
-        # DP noise/clamp kernel (HBM-bound): x = clamp(x + s*N(0,1)), 8 B/element algorithmic
-        n_el = 1 << 28
-        x = torch.zeros(n_el, device=dev)
-        for _ in range(3):
-            ops.noise_add_clamp(x, 1e-3, rng=eng.rng_shared, clamp=0.01)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            ops.noise_add_clamp(x, 1e-3, rng=eng.rng_shared, clamp=0.01)
-        e1.record()
-        torch.cuda.synchronize()
-        gbs = 8.0 * n_el * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        out['dp_noise_clamp'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                 'frac': gbs / HBM_PEAK_GBS, 'elements': n_el}
-        del x
-        # DP clip kernel (per-example Gram / ghost norm, HBM-bound): 3n rows of K0 + d floats read once
-        K0, dd = eng.K0, eng.ddim[0]
-        nn = 16384
-        act = torch.randn(3 * nn, K0, device=dev)
-        dl = torch.randn(3 * nn, dd, device=dev)
-        n2 = torch.zeros(nn, dtype=torch.float64, device=dev)
-        for _ in range(2):
-            ops.persample_gram(dl, act, nn, n2)
-        e0.record()
-        for _ in range(5):
-            ops.persample_gram(dl, act, nn, n2)
-        e1.record()
-        torch.cuda.synchronize()
-        gbs = 4.0 * 3 * nn * (K0 + dd) * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        out['dp_clip_norm'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': gbs / HBM_PEAK_GBS, 'examples': nn, 'row_floats': K0 + dd,
-                               'kernel': 'persample_gram_kernel'}
-        del act, dl, n2
+            out.update(step_kernel_rooflines(eng, eager_step, args))
+        out.update(standalone_dp_kernels(eng, dev))
 
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(eng, span, args)
@@ -208,6 +121,189 @@ def main():
     if dist.rank == 0:
         print(json.dumps(out))
     dist.shutdown()
+
+
+def source_sha():
+    """Identity of the code a profile was taken with: kernels + the host code that decides the launches."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, 'dp_cgans_amd', 'csrc', '*.hip')))
+    files += [os.path.join(ROOT, 'dp_cgans_amd', f) for f in ('engine.py', 'ops.py')]
+    for f in files:
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:12]
+
+
+def trace_figures(args):
+    """Per-kernel figures of the rocprofv3 kernel trace + PMC passes of THIS command (the step replayed as one
+    graph with its side branches: tools/kernel_roofline.py -> profiles/r02_kernel_roofline.json).  They are a
+    record of an earlier run, so they are only quoted when the sources they were taken with are the current
+    ones and the workload is the default one; otherwise None."""
+    path = os.path.join(ROOT, 'profiles', 'r02_kernel_roofline.json')
+    default_wl = (args.table == 'T1M' and args.rows is None and args.batch == 8192 and args.pac == 8
+                  and args.dims == '256,256' and args.d_steps == 1 and args.dp_mode == 'dpsgd')
+    if not default_wl or not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get('source_sha') != source_sha():
+        return None
+    return rec
+
+
+def step_kernel_rooflines(eng, eager_step, args):
+    """Roofline figures of the kernels the timed step runs, measured live: the launches of one training step are
+    logged (identical arguments and buffers), and each kernel family's launches are issued again inside a
+    captured HIP graph of their own - one chain on one stream, so the graph's duration is the sum of the kernel
+    durations, with no host launch gaps - between two HIP events.  In the real step the same kernels share the
+    chip with the step's side branches; that figure comes from the rocprofv3 trace (``in_graph_trace``)."""
+    import torch
+    from dp_cgans_amd._lib import lib
+    L = lib()
+    dev = eng.dev
+    eng.concurrent = False            # one stream: the log is in issue order
+    L.log = []
+    eager_step()
+    torch.cuda.synchronize()
+    log, L.log = L.log, None
+    eng.concurrent = True
+
+    def timed(entries, copies, reps=10):
+        """average duration (us) of one pass over ``entries``"""
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            g.capture_begin()
+            h = torch.cuda.current_stream(dev).cuda_stream
+            for _ in range(copies):
+                for e in entries:
+                    L.replay(e, h)
+            g.capture_end()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / (reps * copies)
+
+    res = {}
+    trace = trace_figures(args)
+    tk = (trace or {}).get('kernels', {})
+    # ---- the dominant kernel: the fp32 MFMA products (gemm_f32_kernel / gemm_ksplit_kernel, all variants)
+    gemms = [e for e in log if e[0] == 'dpc_gemm_f32_ex']
+    flops = sum(e[2]['flops'] for e in gemms)
+    nlaunch = sum(len(e[2]['shapes']) for e in gemms)
+    alg_bytes = sum(e[2]['bytes'] for e in gemms) / nlaunch
+    us = timed(gemms, copies=4)
+    achieved = flops / (us * 1e-6) / 1e12
+    if os.environ.get('DPC_GEMM_BREAKDOWN'):      # per-shape launch times of one step, to stderr
+        for i, e in enumerate(gemms):
+            t = timed([e], copies=20, reps=3)
+            m, n, k, ta, tb = e[2]['shapes'][0]
+            sys.stderr.write('%2d M=%5d N=%5d K=%6d ta=%d tb=%d x%d  %7.1f us %6.1f TF/s\n'
+                             % (i, m, n, k, ta, tb, len(e[2]['shapes']), t, 1e-6 * e[2]['flops'] / t))
+    tg = tk.get('gemm')
+    res['roofline'] = {
+        'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+        'traffic': tg['traffic_bytes_per_launch'] if tg else None,
+        'traffic_unit': 'HBM bytes per launch (TCC_EA0_RDREQ/WRREQ passes of this command, gfx950 correction; '
+                        'tools/pmc_traffic.py)',
+        'algorithmic_bytes_per_launch': alg_bytes,
+        'kernel': 'gemm_f32_kernel + gemm_ksplit_kernel (all tile variants)', 'launches_per_step': nlaunch,
+        'gflop_per_launch': flops / nlaunch / 1e9, 'avg_launch_us': us / nlaunch,
+        'gflop_per_step': flops / 1e9, 'gemm_ms_per_step': us / 1e3,
+        'method': "one step's GEMM launches issued again as one chain inside a captured graph (kernel time, no "
+                  'host gaps), HIP events',
+        'in_graph_trace': None if not tg else {
+            'achieved': tg['achieved'], 'frac': tg['frac'], 'avg_launch_us': tg['avg_us'],
+            'launches_per_step': tg['launches_per_step'],
+            'source': 'profiles/%s (rocprofv3 --kernel-trace --stats of this command: the launches inside the '
+                      'replayed step graph, beside its side branches)' % trace['stats_csv']},
+    }
+    # ---- the DP kernels as the step runs them (HBM-bound; at this size their buffers sit in the 256 MB
+    # Infinity Cache / L2, and n = B / pac examples do not fill the chip: latency, not bandwidth, bounds them)
+    n, M = eng.n, eng.M
+    clip = [e for e in log if e[0] in ('dpc_persample_clip_all_gram', 'dpc_persample_clip_all')]
+    if clip:
+        gram = clip[0][0].endswith('_gram')
+        d = eng.ddim
+        k_in = [eng.K0x if gram else eng.K0] + d[:-1] + [d[-1]]
+        rows_in = [2 * n if gram else 3 * n] + [3 * n] * M
+        by = 4.0 * sum(3 * n * w for w in d + [1]) + 4.0 * sum(r * w for r, w in zip(rows_in, k_in))
+        if gram:
+            by += 4.0 * 2 * (2 * n * d[0])             # the first layer's plain products: read, then cleared
+        us = timed(clip[:1], copies=20)
+        gbs = by / (us * 1e-6) / 1e9
+        t = tk.get('persample_gram_all_kernel')
+        res['dp_clip_norm_in_step'] = {
+            'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'kernel': 'persample_gram_all_kernel', 'examples': n, 'algorithmic_bytes': by, 'launch_us': us,
+            'in_graph_trace': None if not t else {'achieved': t['achieved'], 'frac': t['frac'], 'avg_launch_us': t['avg_us']}}
+    adam = [e for e in log if e[0] == 'dpc_adam_step']
+    if adam and eng.dp_mode == 'dpsgd':
+        dsc = eng.disc
+        saved = [x.clone() for x in (dsc.p, dsc.m, dsc.v, dsc.t)]
+        by = 28.0 * dsc.n                               # p, g, m, v read; p, m, v written; the noise is drawn in registers
+        us = timed(adam[:1], copies=20)
+        for x, y in zip((dsc.p, dsc.m, dsc.v, dsc.t), saved):
+            x.copy_(y)
+        dsc.loaded = True
+        gbs = by / (us * 1e-6) / 1e9
+        t = tk.get('adam_kernel_disc')
+        res['dp_noise_in_step'] = {
+            'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'kernel': 'adam_kernel<true> (Gaussian noise add fused into the discriminator Adam step)',
+            'parameters': dsc.n, 'algorithmic_bytes': by, 'launch_us': us,
+            'in_graph_trace': None if not t else {'achieved': t['achieved'], 'frac': t['frac'], 'avg_launch_us': t['avg_us']}}
+    eng.Zp.zero_()               # the replayed first-layer products added into it
+    torch.cuda.synchronize()
+    return res
+
+
+def standalone_dp_kernels(eng, dev):
+    """The DP clip / noise kernels on buffer sets larger than the Infinity Cache (north_star's >= 60 % of the HBM
+    roofline is stated for these): what the kernels reach when the example count fills the chip."""
+    import torch
+    from dp_cgans_amd import ops
+    out = {}
+    # DP noise/clamp kernel (HBM-bound): x = clamp(x + s*N(0,1)), 8 B/element algorithmic
+    n_el = 1 << 28
+    x = torch.zeros(n_el, device=dev)
+    for _ in range(3):
+        ops.noise_add_clamp(x, 1e-3, rng=eng.rng_shared, clamp=0.01)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.noise_add_clamp(x, 1e-3, rng=eng.rng_shared, clamp=0.01)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 8.0 * n_el * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out['dp_noise_clamp'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': gbs / HBM_PEAK_GBS, 'elements': n_el, 'kernel': 'noise_add_clamp_kernel (stand-alone)'}
+    del x
+    # DP clip kernel (per-example Gram / ghost norm, HBM-bound): 3n rows of K0 + d floats read once
+    K0, dd = eng.K0, eng.ddim[0]
+    nn = 16384
+    act = torch.randn(3 * nn, K0, device=dev)
+    dl = torch.randn(3 * nn, dd, device=dev)
+    n2 = torch.zeros(nn, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        ops.persample_gram(dl, act, nn, n2)
+    e0.record()
+    for _ in range(5):
+        ops.persample_gram(dl, act, nn, n2)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 4.0 * 3 * nn * (K0 + dd) * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out['dp_clip_norm'] = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': gbs / HBM_PEAK_GBS, 'examples': nn, 'row_floats': K0 + dd,
+                           'kernel': 'persample_gram_kernel (stand-alone)'}
+    return out
 
 
 def cpu_baseline(eng, span, args):
@@ -227,7 +323,7 @@ def cpu_baseline(eng, span, args):
     g = torch.Generator().manual_seed(0)
     t_total, steps = 0.0, 0
     sd, sg = {'t': 0, 'm': {}, 'v': {}}, {'t': 0, 'm': {}, 'v': {}}
-    while t_total < 10.0 and steps < 20:
+    while t_total < 12.0 and steps < 60:
         z = torch.randn(B, eng.E, generator=g)
         e = torch.empty(B, Dd).exponential_(generator=g)
         perm = torch.randperm(B, generator=g)

@@ -55,7 +55,22 @@ class _Lib(object):
             fn.restype = restype
             fn.argtypes = argtypes
 
+    # When set to a list, every call is appended as (name, args) - bench.py uses it to issue the launches of one
+    # training step again (replay) for the per-kernel roofline figures.  Measurement aid only.
+    log = None
+
+    def replay(self, entry, stream):
+        """Issue a logged launch again on ``stream`` (every launching entry point takes the stream last)."""
+        name, args = entry[0], entry[1]
+        log, self.log = self.log, None
+        try:
+            self.call(name, *(args[:-1] + (stream,)))
+        finally:
+            self.log = log
+
     def call(self, name, *args):
+        if self.log is not None:
+            self.log.append((name, args))
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             msg = self.cdll.dpc_last_error()

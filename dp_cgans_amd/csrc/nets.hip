@@ -265,6 +265,39 @@ extern "C" int dpc_colreduce_finish(const double* part, int R, int nout, int F, 
   return DPC_OK;
 }
 
+// Fold the R row-chunk partials of a column reduction into ONE fp64 vector per set: out[set][j] = sum_r
+// part[set][r][j], j < width (= nout * F), in the finish kernels' order (lane rl adds chunks rl, rl+4, ..; then
+// (s0 + s1) + (s2 + s3)) - a consumer given the folded vector with R = 1 gets bit-identical sums.  This is what a
+// data-parallel step all-reduces: width doubles per BatchNorm layer instead of R x width.  In place is fine
+// (out == part: every thread reads its column of all chunks before it writes).
+__global__ __launch_bounds__(256) void colreduce_fold_kernel(const double* part, int R, int width, int64_t set_stride,
+                                                             double* out, int64_t out_stride) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const double* p = part + (int64_t)blockIdx.y * set_stride;
+  double s = 0.0;
+  if (j < width) {
+#pragma unroll 8
+    for (int r = rl; r < R; r += 4) s += p[(int64_t)r * width + j];
+  }
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl != 0 || j >= width) return;
+  out[(int64_t)blockIdx.y * out_stride + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+extern "C" int dpc_colreduce_fold(const double* part, int R, int width, int nsets, int64_t set_stride, double* out,
+                                  int64_t out_stride, void* stream) {
+  DPC_CHECK_ARG(part && out, "colreduce_fold: null pointer");
+  DPC_CHECK_ARG(R >= 1 && width > 0 && nsets >= 1 && nsets <= 65535, "colreduce_fold: bad argument");
+  DPC_CHECK_ARG(nsets == 1 || (set_stride >= (int64_t)R * width && out_stride >= width), "colreduce_fold: sets overlap");
+  hipLaunchKernelGGL(colreduce_fold_kernel, dim3((unsigned)dpc_cdiv(width, 64), (unsigned)nsets), dim3(256), 0,
+                     (hipStream_t)stream, part, R, width, set_stride, out, out_stride);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dpc_colsum_noalloc: the weighted column sums of dpc_colreduce_partial(mode 1) + dpc_colreduce_finish
 // (kind 1) in one call whose row-chunk partials live in a file-scope device array instead of a

@@ -331,6 +331,7 @@ class StepEngine(object):
         self.early = torch.cuda.Stream(device=d) if self.dev.type == 'cuda' else None
         self.part_side = [torch.zeros(64 * 2 * maxF, device=d, dtype=torch.float64) for _ in self.side]
         self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
+        self.pair_fold = torch.zeros(4 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
         self._g1_issued = False  # W1 W1^T of this discriminator update is already on its way (_draw_inputs)
         self._pair_sort = False  # _gen_forward_pair issues the hot-id sort at the end of its second lane
@@ -613,8 +614,8 @@ class StepEngine(object):
         for l in range(self.L):
             self._gen_linear(c, l, c.Z[l], g.P('seq.%d.fc.bias' % l), colstat=c.bnacc[l] if self.fused_stats else None)
             part, R = self._bn_sums(c, l, c.bnacc[l])
+            R = self._sync_sums(part, R, 2 * self.gdim[l])
             c.sums[l] = (part, R)
-            self._allreduce(part[:R * 2 * self.gdim[l]])
             ops.bn_relu_fwd_fused(c.Z[l], c.Hg[:, self.start[l + 1]:self.start[l]], part, R, count,
                                   g.P('seq.%d.bn.weight' % l), g.P('seq.%d.bn.bias' % l), c.bn_mean[l], c.bn_invstd[l],
                                   run_mean=self.bn_run['seq.%d.bn.running_mean' % l] if running else None,
@@ -664,6 +665,7 @@ class StepEngine(object):
                 R = ops.colreduce_rows(self.B, F)
                 width = R * 2 * F
                 sums = [self.pair_part[0:width], self.pair_part[width:2 * width]]
+                fold = self.pair_fold[:4 * F]
             with lane_b():
                 self._gen_linear(cb, l, cb.Z[l], b, colstat=sums[1] if self.fused_stats else None)
                 if not self.fused_stats:
@@ -673,7 +675,12 @@ class StepEngine(object):
                 assert ops.colreduce_partial(0, ca.Z[l], sums[0]) == R
             if lanes:
                 main.wait_stream(self.early)
-            self._allreduce(self._bn_pair[l].view(-1) if self.fused_stats else self.pair_part[:2 * width])
+            if self.fused_stats:
+                self._allreduce(self._bn_pair[l].view(-1))
+            else:               # both contexts' partials folded to [2][2F] finished sums: one small all-reduce
+                ops.colreduce_fold(self.pair_part, R, 2 * F, nsets=2, set_stride=width, out=fold, out_stride=2 * F)
+                self._allreduce(fold)
+                sums, R = [fold[0:2 * F], fold[2 * F:4 * F]], 1
             for i, c in enumerate((ca, cb)):
                 if i == 1 and lanes:
                     self.early.wait_stream(main)     # after ca's: the running statistics are updated in sequence order
@@ -874,6 +881,17 @@ class StepEngine(object):
             self._ar_hook(t)
             return t
         return self.dist.allreduce(t)
+
+    def _sync_sums(self, part, R, width):
+        """Data parallel: the R row-chunk partials of a BatchNorm column reduction (``part`` [R, width] fp64) become
+        the sums over the GLOBAL batch - folded on the device to one vector, then ONE all-reduce of `width` doubles
+        (not R x width).  Returns the chunk count to hand to the consumer (1 once folded)."""
+        if not self.dist.active:
+            return R
+        if R > 1:
+            ops.colreduce_fold(part, R, width)
+        self._allreduce(part[:width])
+        return 1
 
     def _colsum(self, x, out, w=None, accumulate=False, part=None):
         part = self.part if part is None else part
@@ -1100,7 +1118,7 @@ class StepEngine(object):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], c.Hg[:, blk]
             R = ops.colreduce_partial(2, dy, self.part, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
-            self._allreduce(self.part[:R * 2 * self.gdim[l]])
+            R = self._sync_sums(self.part, R, 2 * self.gdim[l])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
             # BatchNorm gradients come from all-reduced column sums, i.e. are global already: written
             # times 1/world so that the sum over ranks of the flat gradient buffer leaves them unchanged
@@ -1233,9 +1251,10 @@ class GraphStep(object):
     segment instead (MI355X_MICROARCH.md, row graph-replay-floor).  Every kernel reads its RNG step
     and Adam step counters from device memory, so a replay draws fresh numbers.
 
-    Single GPU: one graph.  Data parallel: the collectives (RCCL all-reduce of BatchNorm sums and
-    of the two flat gradient buffers) stay eager on the same stream and cut the step into graph
-    segments, ``[graph, all-reduce, graph, ...]``.
+    Single GPU: one graph.  Data parallel over RCCL: one graph as well, the all-reduces (BatchNorm sums, the two
+    flat gradient buffers) captured as nodes of it.  Other backends (gloo rehearsals), DPCGAN_GRAPH_COLLECTIVES=0,
+    or a runtime that refuses to capture a collective: the collectives stay eager on the same stream and cut the
+    step into graph segments, ``[graph, all-reduce, graph, ...]``.
     """
 
     def __init__(self, eng, d_steps=1):
@@ -1247,8 +1266,27 @@ class GraphStep(object):
         self.eng.train_step(self.d_steps)
 
     def capture(self):
+        """Capture the step.  With RCCL (backend ``nccl``) the all-reduces are captured INTO the graph - one graph
+        per step, its branches intact - unless DPCGAN_GRAPH_COLLECTIVES=0 or the capture fails (a runtime that
+        refuses a collective on a capturing stream raises there): then, and with any other backend, the
+        collectives stay eager between graph segments."""
+        eng = self.eng
+        in_graph = getattr(eng.dist, 'backend', None) == 'nccl' and os.environ.get('DPCGAN_GRAPH_COLLECTIVES') != '0'
+        if in_graph:
+            try:
+                self._capture(True)
+                return
+            except Exception as ex:             # noqa: BLE001 - whatever the runtime raised, the segment path still works
+                import warnings
+                warnings.warn('dp_cgans_amd: capturing the RCCL collectives into the step graph failed (%s); '
+                              'falling back to eager collectives between graph segments' % (ex,))
+                torch.cuda.synchronize(eng.dev)
+        self._capture(False)
+
+    def _capture(self, in_graph):
         eng = self.eng
         items = []
+        self.collectives_in_graph = in_graph
         self._stream = torch.cuda.Stream(device=eng.dev)
         self._stream.wait_stream(torch.cuda.current_stream(eng.dev))
         batches = eng.bn_batches
@@ -1263,12 +1301,17 @@ class GraphStep(object):
                 state['g'] = torch.cuda.CUDAGraph()
                 state['g'].capture_begin()
 
-            # DPCGAN_GRAPH_COLLECTIVES=1 (experimental, validated on one rank only): the RCCL all-reduces are
-            # captured into the graph instead of cutting it - one graph per step again
-            in_graph = os.environ.get('DPCGAN_GRAPH_COLLECTIVES') == '1' and getattr(eng.dist, 'backend', None) == 'nccl'
             eng._ar_hook = None if in_graph else cut
             try:
                 self._body()
+            except Exception:
+                try:                            # leave capture mode before the error travels on
+                    state['g'].capture_end()
+                except Exception:               # noqa: BLE001
+                    pass
+                eng._open, eng._early_open, eng._early_hook = [], False, None
+                eng.bn_batches = batches
+                raise
             finally:
                 eng._ar_hook = None
             state['g'].capture_end()

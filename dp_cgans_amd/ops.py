@@ -17,12 +17,6 @@ SITE_Z, SITE_GUMBEL, SITE_DROP0, SITE_ALPHA, SITE_CONDVEC, SITE_ROWPICK, SITE_PE
 SITE_NOISE_D, SITE_HOOK, SITE_ENCODE = 7, 8, 9
 
 
-# When set to a list, gemm() brackets every launch with HIP events on the launch stream and appends
-# (start_event, end_event, flops, tag, replay) - replay() issues the identical launch again; bench.py
-# uses it for the live roofline measurement.
-GEMM_PROFILE = None
-
-
 _dev_index = None        # GPU of the tensors of the call being assembled (see _stream)
 
 
@@ -186,6 +180,10 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
         d.seg_b, d.seg_c = int(seg_b), int(seg_c)
         d.seg_len, d.seg_pad, d.seg_stride = int(seg[0]), int(seg[1]), int(seg[2])
     d._flops = 2.0 * M * N * K
+    # bytes the product must move once: both operands, C (read as well when it is accumulated into), the slope /
+    # multiplier matrices of the fused epilogues, the gathered rows
+    d._bytes = 4.0 * (M * K + K * N + M * N * (1 + (beta != 0.0) + (aux_out is not None) + (aux_in is not None)
+                                                + 2 * (gat is not None)))
     d._shape = (M, N, K, trans_a, trans_b)
     return d
 
@@ -194,16 +192,11 @@ def gemm_run(descs):
     """Issue the products of ``descs`` (list of gemm_desc results) in order with ONE library call."""
     n = len(descs)
     arr = (GemmDesc * n)(*descs)
-    prof = GEMM_PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    st = _stream()
-    lib().call('dpc_gemm_f32_ex', ctypes.byref(arr), n, st)
-    if prof is not None:
-        e1.record()
-        prof.append((e0, e1, sum(d._flops for d in descs), descs[0]._shape,
-                     lambda: lib().call('dpc_gemm_f32_ex', ctypes.byref(arr), n, _stream())))
+    L = lib()
+    L.call('dpc_gemm_f32_ex', ctypes.byref(arr), n, _stream())
+    if L.log is not None:       # (bench.py's launch log: what this launch computes, for the roofline figures)
+        L.log[-1] = L.log[-1] + (dict(flops=sum(d._flops for d in descs), bytes=sum(d._bytes for d in descs),
+                                       shapes=[d._shape for d in descs]),)
 
 
 def gemm(A, B, C, **kw):
@@ -425,6 +418,14 @@ def colreduce_finish(part, R, nout, F, kind, out0, out1=None, count=1.0, eps=1e-
                      run_var=None, accumulate=False):
     lib().call('dpc_colreduce_finish', _p(part), R, nout, F, kind, float(count), eps, momentum, _p(out0), _p(out1),
                _p(run_mean), _p(run_var), int(accumulate), _stream())
+
+
+def colreduce_fold(part, R, width, nsets=1, set_stride=0, out=None, out_stride=0):
+    """Fold R row-chunk partials [R, width] (per set) into one fp64 vector each, in place unless ``out`` is given."""
+    _chk(part, torch.float64, 'part')
+    _chk(out, torch.float64, 'out')
+    lib().call('dpc_colreduce_fold', _p(part), R, width, nsets, set_stride, _p(part if out is None else out),
+               out_stride if out is not None else set_stride, _stream())
 
 
 def colsum_multi(problems, part, accumulate=False):

@@ -276,6 +276,12 @@ int dpc_colreduce_partial(int mode, const float* x, int64_t ldx, int64_t rows, i
 int dpc_colreduce_finish(const double* part, int R, int nout, int F, int kind, double count, float eps,
                          float momentum, float* out0, float* out1, float* run_mean, float* run_var,
                          int accumulate, void* stream);
+/* out[set*out_stride + j] = sum_r part[set*set_stride + r*width + j], j < width = nout*F, in dpc_colreduce_finish's
+ * summation order: the ONE fp64 vector per BatchNorm layer that a data-parallel step all-reduces (sync BatchNorm:
+ * the batch statistics of dp_cgan.py:76 over the global batch) instead of the R row-chunk partials; a consumer
+ * given it with R = 1 computes bit-identical sums.  out may be part (in place). */
+int dpc_colreduce_fold(const double* part, int R, int width, int nsets, int64_t set_stride, double* out,
+                       int64_t out_stride, void* stream);
 /* n (<= 8) weighted column sums out_p[f] (+)= sum_r w_p[r] * x_p[r*ldx_p + f] in two launches for all of them:
  * the bias gradients and the head layer's weight gradient of one backward pass (autograd of the Linear
  * layers, dp_cgan.py:40,43,75,95).  All array arguments are HOST arrays of n entries, w[p] nullable; part:

@@ -104,8 +104,8 @@ def graph(dist, dev, mode):
     for _ in range(4):
         gs.run()
     torch.cuda.synchronize()
-    if os.environ.get('DPCGAN_GRAPH_COLLECTIVES') == '1' and dist.backend == 'nccl':
-        assert len(gs.items) == 1, 'collectives captured: one graph per step'
+    if os.environ.get('DPCGAN_GRAPH_COLLECTIVES') != '0' and dist.backend == 'nccl':
+        assert len(gs.items) == 1 and gs.collectives_in_graph, 'RCCL collectives are captured: one graph per step'
     else:
         assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
     assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)

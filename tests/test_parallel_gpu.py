@@ -61,6 +61,10 @@ def test_rccl_single_rank_replays_the_reference_trace():
     launch(['replay'], world=1, extra_env=RCCL1)
 
 
+@pytest.mark.parametrize('collectives', ['in-graph', 'between-segments'])
 @pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
-def test_rccl_single_rank_graph_segments_equal_eager(mode):
-    launch(['graph', mode], world=1, extra_env=RCCL1)
+def test_rccl_single_rank_graph_replay_equals_eager(mode, collectives):
+    """GraphStep over RCCL: by default the all-reduces are nodes of the one step graph; DPCGAN_GRAPH_COLLECTIVES=0
+    keeps them eager between graph segments (the fallback).  Both bit-equal to the eager step."""
+    env = dict(RCCL1, DPCGAN_GRAPH_COLLECTIVES='1' if collectives == 'in-graph' else '0')
+    launch(['graph', mode], world=1, extra_env=env)

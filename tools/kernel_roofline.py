@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table of the graph-replayed training step, from the rocprofv3 records of ONE command:
+
+  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -o bench -- python3 bench.py --no-cpu-baseline
+  rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-graph
+  rocprofv3 --pmc WRITE_SIZE -- (same)
+
+usage: kernel_roofline.py --trace <bench_kernel_trace.csv> --bench <stdout of that bench run (its JSON line)>
+                          --stats-name <file name of the kernel_stats.csv as committed under profiles/>
+                          [--fetch <counter_collection.csv> --write <counter_collection.csv>] --out profiles/r02_kernel_roofline.json
+
+The trace is cut into training steps at rng_advance_kernel (the last node of the step graph); the `steps` timed
+replays of the bench run (after its warm-up) are averaged: launches per step and average duration of every kernel
+as it runs INSIDE the step graph, beside the graph's side branches.  Algorithmic work per kernel follows DESIGN.md
+section 4 (bytes each kernel must move once, flops of the products); achieved = work / time, frac = achieved / peak
+(HBM 8 TB/s, fp32 MFMA 157.3 TF/s: MI355X_MICROARCH.md).  HBM-side traffic of the products: FETCH_SIZE x 2 +
+WRITE_SIZE in KiB per dispatch (the guide's gfx950 correction: FETCH_SIZE counts 64 B per 128-B request).
+bench.py quotes these figures (``in_graph_trace``, ``traffic``) only while source_sha matches the current sources.
+"""
+import argparse
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, source_sha  # noqa: E402
+
+
+def family(name):
+    n = name.replace('void ', '')
+    n = n.split('(')[0]
+    if n.startswith('gemm_f32_kernel') or n.startswith('gemm_ksplit_kernel'):
+        return 'gemm'
+    if n.startswith('at::native') or n.startswith('__amd_rocclr'):
+        return 'torch fill / copy (zero pools)'
+    return n.strip()
+
+
+def algorithmic_bytes_per_step(c):
+    """DESIGN.md section 4, per training step (1 discriminator + 1 generator update) and kernel family."""
+    B, Dd, C, pac = c['batch'], c['data_dim'], c['cond_dim'], c['pac']
+    n = B // pac
+    g, d = c['gen_dims'], c['disc_dims']
+    K0x = c['k0_compact']
+    M = len(d)
+    clip = 4.0 * sum(3 * n * w for w in d + [1]) + 4.0 * (2 * n * K0x + sum(3 * n * w for w in d[:-1] + [d[-1]])) + 16.0 * n * d[0]
+    return {
+        'activate_fwd_small_kernel<false>': 8.0 * B * Dd,                 # raw in, activated out (D update's fake rows)
+        'activate_fwd_small_kernel<true>': 12.0 * B * Dd,                 # + the cond loss gradient written
+        'activate_bwd_tiled_kernel<true>': 16.0 * B * Dd,                 # y, dy, loss gradient in; d raw out
+        'persample_gram_all_kernel': clip,
+        'adam_kernel_disc': 28.0 * c['disc_params'],
+        'adam_kernel_gen': 28.0 * c['gen_params'],
+        'row_gather_kernel': 8.0 * B * Dd,
+        'bn_relu_fwd_fused_kernel': 2 * sum(8.0 * B * w for w in g),     # both generator forwards of the step
+        'bn_relu_bwd_fused_kernel': sum(16.0 * B * w for w in g),
+        'colreduce_kernel<2>': sum(12.0 * B * w for w in g),
+        'disc_out_kernel': 12.0 * (3 * n + n) * d[-1],
+        'gp_gram_rows_kernel': 16.0 * n * d[0],
+        'disc_first_act_kernel<true>': 4.0 * d[0] * ((2 * n + 2 * 3 * n + 2 * n) + (n + 2 * n)),
+        'condvec_pair_kernel': 2 * (4.0 * B * 2 + 4.0 * B * c['n_discrete']),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--trace', required=True)
+    ap.add_argument('--bench', required=True)
+    ap.add_argument('--stats-name', required=True)
+    ap.add_argument('--fetch')
+    ap.add_argument('--write')
+    ap.add_argument('--mfma', help='counter_collection.csv of the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass')
+    ap.add_argument('--out', required=True)
+    a = ap.parse_args()
+
+    line = [l for l in open(a.bench) if l.startswith('{')][-1]
+    bench = json.loads(line)
+    cfg = bench['config']
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if 'rng_advance_kernel' in r[2]]
+    warm, steps = max(bench['warmup'], 2), bench['steps']
+    # step k of the run = rows (ends[k-1], ends[k]]; the timed replays are steps warm .. warm+steps-1
+    per = collections.defaultdict(lambda: [0, 0.0])
+    span_us = 0.0
+    for k in range(warm, warm + steps):
+        lo, hi = ends[k - 1] + 1, ends[k] + 1
+        span_us += (rows[hi - 1][1] - rows[lo - 1][1]) / 1e3
+        seen_adam = 0
+        for s, e, name in rows[lo:hi]:
+            fam = family(name)
+            if fam.startswith('adam_kernel'):
+                fam = 'adam_kernel_disc' if seen_adam == 0 else 'adam_kernel_gen'
+                seen_adam += 1
+            per[fam][0] += 1
+            per[fam][1] += (e - s) / 1e3
+    alg = algorithmic_bytes_per_step(cfg)
+    kernels = {}
+    for fam, (cnt, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        ent = {'launches_per_step': cnt / steps, 'avg_us': us / cnt, 'us_per_step': us / steps}
+        if fam == 'gemm':
+            gf = bench['roofline']['gflop_per_step']
+            ach = gf * 1e9 / (us / steps * 1e-6) / 1e12
+            ent.update(bound='mfma', gflop_per_step=gf, achieved=ach, unit='TFLOP/s', peak=FP32_MFMA_PEAK_TFLOPS,
+                       frac=ach / FP32_MFMA_PEAK_TFLOPS,
+                       algorithmic_bytes_per_launch=bench['roofline']['algorithmic_bytes_per_launch'])
+        elif fam in alg:
+            ach = alg[fam] / (us / steps * 1e-6) / 1e9
+            ent.update(bound='hbm', algorithmic_bytes_per_step=alg[fam], achieved=ach, unit='GB/s', peak=HBM_PEAK_GBS,
+                       frac=ach / HBM_PEAK_GBS)
+        else:
+            ent.update(bound='latency / index work', note='a few hundred KB per launch: bounded by launch + dependency latency')
+        kernels[fam] = ent
+    if a.fetch and a.write:
+        def per_kernel(path):
+            v = []
+            for r in csv.DictReader(open(path)):
+                if family(r['Kernel_Name']) == 'gemm':
+                    v.append(float(r['Counter_Value']))
+            return v
+        gf, gw = per_kernel(a.fetch), per_kernel(a.write)
+        kernels['gemm'].update(
+            traffic_bytes_per_launch=(2.0 * sum(gf) / len(gf) + sum(gw) / len(gw)) * 1024.0,
+            fetch_size_kib_avg=sum(gf) / len(gf), write_size_kib_avg=sum(gw) / len(gw), fetch_correction=2.0,
+            traffic_launches=len(gf),
+            traffic_command='rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 3 --warmup 2 '
+                            '--no-cpu-baseline --no-roofline --no-graph')
+        kernels['gemm']['traffic_over_algorithmic'] = (kernels['gemm']['traffic_bytes_per_launch']
+                                                       / kernels['gemm']['algorithmic_bytes_per_launch'])
+    if a.mfma:
+        # matrix-core busy share of the products: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs
+        # (64 per v_mfma_f32_32x32x2_f32: the sum equals flops / 64 for full tiles), GRBM_GUI_ACTIVE the busy cycles
+        # summed over the 8 XCDs (MI355X_MICROARCH.md)
+        acc = collections.defaultdict(float)
+        for r in csv.DictReader(open(a.mfma)):
+            if family(r['Kernel_Name']) == 'gemm':
+                acc[r['Counter_Name']] += float(r['Counter_Value'])
+        kernels['gemm'].update(
+            mfma_busy_cycles=acc['SQ_VALU_MFMA_BUSY_CYCLES'], gui_active_cycles_sum_xcd=acc['GRBM_GUI_ACTIVE'],
+            mfma_util=acc['SQ_VALU_MFMA_BUSY_CYCLES'] / (acc['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0),
+            wave_cycles={k: acc[k] for k in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY', 'SQ_BUSY_CU_CYCLES')},
+            mfma_command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY '
+                         'SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 2 '
+                         '--no-cpu-baseline --no-roofline --no-graph (launches serialised by the counter collection)')
+    out = {
+        'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline',
+        'workload': cfg['workload'], 'source_sha': source_sha(), 'stats_csv': a.stats_name,
+        'steps_averaged': steps, 'step_us_in_trace': span_us / steps, 'bench_ms_per_step_under_rocprof': bench['ms_per_step'],
+        'kernel_us_per_step': sum(v['us_per_step'] for v in kernels.values()),
+        'kernels': kernels,
+    }
+    json.dump(out, open(a.out, 'w'), indent=1)
+    for fam, v in kernels.items():
+        print('%-40s %5.1f x %7.1f us  %s' % (fam, v['launches_per_step'], v['avg_us'],
+                                             ('%8.1f %s  frac %.3f' % (v['achieved'], v['unit'], v['frac'])) if 'achieved' in v else ''))
+    print('step %.1f us in trace; sum of kernel time %.1f us' % (out['step_us_in_trace'], out['kernel_us_per_step']))
+
+
+if __name__ == '__main__':
+    main()
