@@ -145,6 +145,22 @@ __device__ __forceinline__ T dpc_wave_sum(T v) {
   return v;
 }
 
+// fp32 sum over the 64 lanes with DPP adds only (row_shr 1/2/3, 4, 8, then row_bcast 15 and 31: the gfx9 sequence) -
+// seven VALU instructions and no LDS traffic, where the __shfl_xor butterfly above issues six ds_bpermute round
+// trips per value (twelve for a double).  The sum comes back in every lane (read from lane 63 into an SGPR).
+#define DPC_DPP(x, ctrl, row_mask, bank_mask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (row_mask), (bank_mask), false))
+__device__ __forceinline__ float dpc_wave_sum_dpp(float v) {
+  float s = v + DPC_DPP(v, 0x111, 0xf, 0xf);  // row_shr:1
+  s += DPC_DPP(v, 0x112, 0xf, 0xf);           // row_shr:2
+  s += DPC_DPP(v, 0x113, 0xf, 0xf);           // row_shr:3  -> s[i] = v[i-3 .. i] within a row of 16
+  s += DPC_DPP(s, 0x114, 0xf, 0xe);           // row_shr:4, banks 1-3
+  s += DPC_DPP(s, 0x118, 0xf, 0xc);           // row_shr:8, banks 2-3  -> lane 15 of each row holds the row's sum
+  s += DPC_DPP(s, 0x142, 0xa, 0xf);           // row_bcast:15 into rows 1 and 3
+  s += DPC_DPP(s, 0x143, 0xc, 0xf);           // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
+}
+
 // Sum over a block of up to 1024 threads; result valid in every thread.  smem: >= 16 elements.
 template <typename T>
 __device__ __forceinline__ T dpc_block_sum(T v, T* smem) {

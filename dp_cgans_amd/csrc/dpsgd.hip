@@ -21,16 +21,18 @@ struct GramArgs {
 
 // 6 unique entries of the symmetric 3x3 Gram of rows r0, r1, r2 (each `len` long): this thread's
 // strided share.  VEC: 16-byte loads (rows 16-byte aligned, len % 4 == 0).
+// (first, step): the positions this thread takes - threadIdx.x, blockDim.x for a whole block; lane, 64 for one wave.
 template <bool VEC>
 __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, const float* __restrict__ r1,
-                                              const float* __restrict__ r2, int len, float g[6]) {
+                                              const float* __restrict__ r2, int len, float g[6], const int first,
+                                              const int step) {
 #pragma unroll
   for (int q = 0; q < 6; ++q) g[q] = 0.f;
   if (VEC) {
     const float4* a = reinterpret_cast<const float4*>(r0);
     const float4* b = reinterpret_cast<const float4*>(r1);
     const float4* c = reinterpret_cast<const float4*>(r2);
-    const int n4 = len >> 2, bd = blockDim.x;
+    const int n4 = len >> 2, bd = step;
     auto fma6 = [&](const float4& x, const float4& y, const float4& z) {
       g[0] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
       g[1] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
@@ -39,7 +41,7 @@ __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, cons
       g[4] += y.x * z.x + y.y * z.y + y.z * z.z + y.w * z.w;
       g[5] += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
     };
-    int j = threadIdx.x;
+    int j = first;
     // four positions (12 loads) in flight per thread: with a few thousand examples per batch the
     // launch is a few blocks per CU and nothing else hides the memory latency
     for (; j + 3 * bd < n4; j += 4 * bd) {
@@ -57,7 +59,7 @@ __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, cons
       fma6(x, y, z);
     }
   } else {
-    for (int j = threadIdx.x; j < len; j += blockDim.x) {
+    for (int j = first; j < len; j += step) {
       float x = r0[j], y = r1[j], z = r2[j];
       g[0] += x * x; g[1] += x * y; g[2] += x * z; g[3] += y * y; g[4] += y * z; g[5] += z * z;
     }
@@ -67,18 +69,18 @@ __device__ __forceinline__ void gram3_partial(const float* __restrict__ r0, cons
 // This thread's share of x.x, x.y, y.y for two rows.
 template <bool VEC>
 __device__ __forceinline__ void gram2_partial(const float* __restrict__ r0, const float* __restrict__ r1, int len,
-                                              float& xx, float& xy, float& yy) {
+                                              float& xx, float& xy, float& yy, const int first, const int step) {
   xx = xy = yy = 0.f;
   if (VEC) {
     const float4* a = reinterpret_cast<const float4*>(r0);
     const float4* b = reinterpret_cast<const float4*>(r1);
-    const int n4 = len >> 2, bd = blockDim.x;
+    const int n4 = len >> 2, bd = step;
     auto fma3 = [&](const float4& x, const float4& y) {
       xx += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
       xy += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       yy += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
     };
-    int j = threadIdx.x;
+    int j = first;
     for (; j + 3 * bd < n4; j += 4 * bd) {      // 8 loads in flight per thread
       float4 x0 = a[j], y0 = b[j], x1 = a[j + bd], y1 = b[j + bd];
       float4 x2 = a[j + 2 * bd], y2 = b[j + 2 * bd], x3 = a[j + 3 * bd], y3 = b[j + 3 * bd];
@@ -92,7 +94,7 @@ __device__ __forceinline__ void gram2_partial(const float* __restrict__ r0, cons
       fma3(x, y);
     }
   } else {
-    for (int j = threadIdx.x; j < len; j += blockDim.x) {
+    for (int j = first; j < len; j += step) {
       float x = r0[j], y = r1[j];
       xx += x * x; xy += x * y; yy += y * y;
     }
@@ -101,9 +103,10 @@ __device__ __forceinline__ void gram2_partial(const float* __restrict__ r0, cons
 
 // This thread's share of u.a and u.b (short rows: the first layer's width).
 __device__ __forceinline__ void dot2_partial(const float* __restrict__ u, const float* __restrict__ a,
-                                             const float* __restrict__ b, int len, float& ua, float& ub) {
+                                             const float* __restrict__ b, int len, float& ua, float& ub, const int first,
+                                             const int step) {
   ua = ub = 0.f;
-  for (int j = threadIdx.x; j < len; j += blockDim.x) {
+  for (int j = first; j < len; j += step) {
     float x = u[j];
     ua += x * a[j];
     ub += x * b[j];
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256) void persample_gram_kernel(GramArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
     float g[12];
-    gram3_partial<VEC_D>(a.delta + i * a.ldd, a.delta + (a.n + i) * a.ldd, a.delta + (2 * a.n + i) * a.ldd, a.d, g);
-    gram3_partial<VEC_A>(a.act + i * a.lda, a.act + (a.n + i) * a.lda, a.act + (2 * a.n + i) * a.lda, a.K, g + 6);
+    gram3_partial<VEC_D>(a.delta + i * a.ldd, a.delta + (a.n + i) * a.ldd, a.delta + (2 * a.n + i) * a.ldd, a.d, g, threadIdx.x, blockDim.x);
+    gram3_partial<VEC_A>(a.act + i * a.lda, a.act + (a.n + i) * a.lda, a.act + (2 * a.n + i) * a.lda, a.K, g + 6, threadIdx.x, blockDim.x);
     // wavefront-level reduction of the 12 partial dot products, then 4 waves through LDS
     double s[12];
 #pragma unroll
@@ -184,10 +187,12 @@ struct GramAllArgs {
   const int32_t* sel_a; const int32_t* sel_b; int pac;
 };
 
-// |A|, |B| and |A n B| summed over the pac sub-rows of example i, A / B = the sets of hot ids of a sub-row
-__device__ __forceinline__ void cond_gram_counts(const GramAllArgs& a, int64_t i, double& aa, double& ab, double& bb) {
+// |A|, |B| and |A n B| summed over the pac sub-rows of example i, A / B = the sets of hot ids of a sub-row: this
+// lane's share (sub-rows first, first + step, ..)
+__device__ __forceinline__ void cond_gram_counts(const GramAllArgs& a, int64_t i, float& aa, float& ab, float& bb,
+                                                 const int first, const int step) {
   int naa = 0, nab = 0, nbb = 0;
-  for (int s = 0; s < a.pac; ++s) {
+  for (int s = first; s < a.pac; s += step) {
     const int64_t q = (i * a.pac + s) * 2;
     const int a0 = a.sel_a[q], a1 = a.sel_a[q + 1], b0 = a.sel_b[q], b1 = a.sel_b[q + 1];
     const bool va0 = a0 >= 0, va1 = a1 >= 0 && a1 != a0, vb0 = b0 >= 0, vb1 = b1 >= 0 && b1 != b0;
@@ -195,64 +200,102 @@ __device__ __forceinline__ void cond_gram_counts(const GramAllArgs& a, int64_t i
     nbb += (int)vb0 + (int)vb1;
     nab += (int)(va0 && ((vb0 && a0 == b0) || (vb1 && a0 == b1))) + (int)(va1 && ((vb0 && a1 == b0) || (vb1 && a1 == b1)));
   }
-  aa = naa; ab = nab; bb = nbb;
+  aa = (float)naa; ab = (float)nab; bb = (float)nbb;       // (exact: counts far below 2^24)
 }
 
-__global__ __launch_bounds__(256) void persample_gram_all_kernel(GramAllArgs a) {
-  __shared__ double red[4][12];
+// One block of GA_WAVES waves per example.  The example's work is a list of ITEMS - per layer the 3x3 Gram of its
+// three delta rows and the one of its three input rows, plus (implicit penalty row) the two dot products with the
+// first layer's plain products.  Most items are a few short rows (the layer widths: 64 16-byte loads per row at
+// width 256), and a block that walked them one after the other - load, block-wide reduction, barrier, next layer -
+// spent its time in latency chains with three waves out of four idle (27 us at T1M for 40 MB, all of it in L2 /
+// Infinity Cache).  Here a short item belongs to ONE wave (item k to wave k % GA_WAVES: the items proceed side by
+// side), a long one (>= GA_LONG floats per row: the K0-wide input rows) is strided over all waves; every wave
+// leaves its wave-summed fp64 entries in LDS, ONE barrier, and thread 0 combines the layers.
+#define GA_WAVES 4
+#define GA_LONG 1024
+__global__ __launch_bounds__(64 * GA_WAVES) void persample_gram_all_kernel(GramAllArgs a) {
+  __shared__ double red[2 * DPC_MAX_LAYERS + 2][GA_WAVES][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nitems = 2 * a.nlayers + (a.zpre ? 1 : 0) + (a.sel_a ? 1 : 0);       // (sel_a goes with zpre)
   for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
-    double total = 0.0;                                   // meaningful in thread 0 only
-    for (int l = 0; l < a.nlayers; ++l) {
-      float g[12];
-      const float* dl = a.delta[l];
-      const float* ac = a.act[l];
-      if (a.vec_d[l]) gram3_partial<true>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
-      else gram3_partial<false>(dl + i * a.ldd[l], dl + (a.n + i) * a.ldd[l], dl + (2 * a.n + i) * a.ldd[l], a.d[l], g);
-      const bool implicit = (l == 0 && a.zpre != nullptr);
-      if (implicit) {
-        if (a.vec_a[l]) gram2_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], a.K[l], g[6], g[7], g[9]);
-        else gram2_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], a.K[l], g[6], g[7], g[9]);
-        dot2_partial(dl + (2 * a.n + i) * a.ldd[l], a.zpre + i * a.ldz, a.zpre + (a.n + i) * a.ldz, a.d[l], g[8], g[10]);
-        g[11] = 0.f;
+    if (i != (int64_t)blockIdx.x) __syncthreads();          // red[] of the previous example has been consumed
+    for (int k = 0; k < nitems; ++k) {
+      float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int l = k >> 1;
+      const bool is_cnt = (k == 2 * a.nlayers + 1);
+      const bool is_dot = (k == 2 * a.nlayers), is_act = !is_dot && !is_cnt && (k & 1);
+      const int len = is_cnt ? a.pac : (is_dot ? a.d[0] : (is_act ? a.K[l] : a.d[l]));
+      const bool spread = len >= GA_LONG;
+      if (!spread && (k % GA_WAVES) != wave) continue;
+      const int first = spread ? (int)threadIdx.x : lane, step = spread ? 64 * GA_WAVES : 64;
+      if (is_cnt) {
+        cond_gram_counts(a, i, g[0], g[1], g[3], first, step);
+      } else if (is_dot) {
+        const float* u = a.delta[0] + (2 * a.n + i) * a.ldd[0];
+        dot2_partial(u, a.zpre + i * a.ldz, a.zpre + (a.n + i) * a.ldz, len, g[0], g[1], first, step);
         if (a.zero) {
-          for (int j = threadIdx.x; j < a.d[l]; j += blockDim.x) {      // the elements this thread just read
+          for (int j = first; j < len; j += step) {          // the elements this thread just read
             a.zero[i * a.ldz + j] = 0.f;
             a.zero[(a.n + i) * a.ldz + j] = 0.f;
           }
         }
-      } else if (a.vec_a[l]) gram3_partial<true>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
-      else gram3_partial<false>(ac + i * a.lda[l], ac + (a.n + i) * a.lda[l], ac + (2 * a.n + i) * a.lda[l], a.K[l], g + 6);
-      double s[12];
-#pragma unroll
-      for (int q = 0; q < 12; ++q) s[q] = dpc_wave_sum((double)g[q]);
-      __syncthreads();
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) red[wave][q] = s[q];
+      } else if (is_act) {
+        const float* ac = a.act[l];
+        const int64_t ld = a.lda[l];
+        if (l == 0 && a.zpre != nullptr) {
+          if (a.vec_a[l]) gram2_partial<true>(ac + i * ld, ac + (a.n + i) * ld, len, g[0], g[1], g[3], first, step);
+          else gram2_partial<false>(ac + i * ld, ac + (a.n + i) * ld, len, g[0], g[1], g[3], first, step);
+        } else if (a.vec_a[l]) gram3_partial<true>(ac + i * ld, ac + (a.n + i) * ld, ac + (2 * a.n + i) * ld, len, g, first, step);
+        else gram3_partial<false>(ac + i * ld, ac + (a.n + i) * ld, ac + (2 * a.n + i) * ld, len, g, first, step);
+      } else {
+        const float* dl = a.delta[l];
+        const int64_t ld = a.ldd[l];
+        if (a.vec_d[l]) gram3_partial<true>(dl + i * ld, dl + (a.n + i) * ld, dl + (2 * a.n + i) * ld, len, g, first, step);
+        else gram3_partial<false>(dl + i * ld, dl + (a.n + i) * ld, dl + (2 * a.n + i) * ld, len, g, first, step);
       }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double t[12];
 #pragma unroll
-        for (int q = 0; q < 12; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-        if (implicit) {
+      for (int q = 0; q < 6; ++q) {
+        const double sq = (double)dpc_wave_sum_dpp(g[q]);
+        if (lane == 0) red[k][wave][q] = sq;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      auto item = [&](int k, int len, double* t) {           // the finished entries of item k
+        if (len >= GA_LONG) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            double sq = 0.0;
+            for (int w = 0; w < GA_WAVES; ++w) sq += red[k][w][q];
+            t[q] = sq;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) t[q] = red[k][k % GA_WAVES][q];
+        }
+      };
+      double total = 0.0;
+      for (int l = 0; l < a.nlayers; ++l) {
+        double t[12];
+        item(2 * l, a.d[l], t);
+        item(2 * l + 1, a.K[l], t + 6);
+        if (l == 0 && a.zpre != nullptr) {
+          double z[6];
+          item(2 * a.nlayers, a.d[0], z);
           if (a.sel_a) {
-            double aa, ab, bb;
-            cond_gram_counts(a, i, aa, ab, bb);
-            t[6] += aa; t[7] += ab; t[9] += bb;
+            double c[6];
+            item(2 * a.nlayers + 1, a.pac, c);
+            t[6] += c[0]; t[7] += c[1]; t[9] += c[3];
           }
           const double f = (double)a.gp_f[i];
-          t[8] *= f;
-          t[10] *= f;
+          t[8] = z[0] * f;
+          t[10] = z[1] * f;
           t[11] = f * f * a.gp_q[i];
         }
         double v = t[0] * t[6] + t[3] * t[9] + t[5] * t[11] + 2.0 * (t[1] * t[7] + t[2] * t[8] + t[4] * t[10]);
         v += t[0] + 2.0 * t[1] + t[3];                     // bias: ||delta_0 + delta_1||^2
         total += v;
       }
-    }
-    if (threadIdx.x == 0) {
       a.norm2[i] = total;
       float nrm = a.gscale * (float)sqrt(total);
       float c = nrm > a.clip ? a.clip / nrm : 1.f;
@@ -291,7 +334,7 @@ static int persample_clip_all_impl(int nlayers, const float* const* delta, const
   a.rowc_w = rowc_w; a.norm_out = norm_out;
   a.zpre = zpre; a.ldz = ldz; a.gp_f = gp_f; a.gp_q = gp_q; a.fc_out = fc_out; a.zero = clear_zpre ? zpre : nullptr;
   a.sel_a = sel_a; a.sel_b = sel_b; a.pac = pac;
-  hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(256), 0,
+  hipLaunchKernelGGL(persample_gram_all_kernel, dim3((unsigned)(n < 16384 ? n : 16384)), dim3(64 * GA_WAVES), 0,
                      (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
