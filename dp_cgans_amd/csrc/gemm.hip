@@ -64,6 +64,11 @@ struct GemmArgs {
   // with fp64 atomics - BatchNorm1d's batch statistics taken where the Linear's output tile still sits in
   // registers (dp_cgan.py:75-76).  fp32 sums over the 32 rows of an MFMA tile, fp64 across tiles.
   double* colstat;
+  // BatchNorm-backward form of the statistics (bn_y != NULL): over the first stat_n columns of the FINAL result
+  // dy (after beta * C), colstat[n] += sum_m dyh, colstat[stat_n + n] += sum_m dyh * xhat with dyh = dy where the
+  // block's ReLU output bn_y is positive (else 0) and xhat = (bn_z - mean[n]) * invstd[n]
+  const float* bn_y; int64_t ld_bn_y; const float* bn_z; int64_t ld_bn_z; const float* bn_mean; const float* bn_invstd;
+  int stat_n;
   int force_atomic;      // add the result to C with fp32 atomics even without split-K (another product adds to C meanwhile)
 };
 
@@ -394,8 +399,10 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
       ocol = col + (int64_t)sgm * (g.seg_stride - g.seg_pad);
     }
     float cs0 = 0.f, cs1 = 0.f;
+    const bool bnb = g.bn_y != nullptr && col < g.stat_n;
     if (live) {
       const float bv = (g.bias && add_bias) ? g.bias[col] : 0.f;
+      const float bmu = bnb ? g.bn_mean[col] : 0.f, bis = bnb ? g.bn_invstd[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
@@ -406,8 +413,10 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
             atomicAdd(cp, v);
           } else {
             if (gather) v += lds[(row - m0) * BN + (col - n0)];
-            cs0 += v;
-            cs1 += v * v;
+            if (!g.bn_y) {
+              cs0 += v;
+              cs1 += v * v;
+            }
             if (g.epi == EPI_LEAKY_DROPOUT) {
               float keep;
               if (g.keep) {
@@ -425,6 +434,11 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
             }
             if (g.beta != 0.f) v += g.beta * (*cp);
             *cp = v;
+            if (bnb) {
+              const float dyh = g.bn_y[(int64_t)row * g.ld_bn_y + col] > 0.f ? v : 0.f;
+              cs0 += dyh;
+              cs1 += dyh * ((g.bn_z[(int64_t)row * g.ld_bn_z + col] - bmu) * bis);
+            }
           }
         }
       }
@@ -432,9 +446,9 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     if (g.colstat) {             // (block-uniform; both lane halves hold the same column)
       cs0 += __shfl_xor(cs0, 32, 64);
       cs1 += __shfl_xor(cs1, 32, 64);
-      if (lk == 0 && live) {
+      if (lk == 0 && live && col < g.stat_n) {
         atomicAdd(g.colstat + col, (double)cs0);
-        atomicAdd(g.colstat + g.N + col, (double)cs1);
+        atomicAdd(g.colstat + g.stat_n + col, (double)cs1);
       }
     }
   };
@@ -667,6 +681,11 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   // segment maps (GemmArgs::seg_*)
   g.seg_b = d.seg_b; g.seg_c = d.seg_c; g.seg_len = d.seg_len; g.seg_pad = d.seg_pad; g.seg_stride = d.seg_stride;
   g.colstat = d.colstat;
+  g.bn_y = d.bn_y; g.ld_bn_y = d.ld_bn_y; g.bn_z = d.bn_z; g.ld_bn_z = d.ld_bn_z; g.bn_mean = d.bn_mean; g.bn_invstd = d.bn_invstd;
+  g.stat_n = d.bn_y ? d.stat_n : N;
+  DPC_CHECK_ARG(!d.bn_y || (d.colstat && d.bn_z && d.bn_mean && d.bn_invstd && d.stat_n >= 1 && d.stat_n <= N &&
+                            d.ld_bn_y >= d.stat_n && d.ld_bn_z >= d.stat_n && (beta == 0.f || beta == 1.f)),
+                "gemm: BatchNorm-backward statistics need colstat, y, z, mean, invstd and 1 <= stat_n <= N");
   g.force_atomic = d.atomic ? 1 : 0;
   DPC_CHECK_ARG(!d.atomic || (beta == 1.f && epi == EPI_NONE && !d.bias && !d.gat && !d.colstat && d.tile != 32 && d.tile != 324),
                 "gemm: atomic accumulation needs beta == 1 and a plain product");

@@ -253,12 +253,14 @@ class StepEngine(object):
             spec += [('dWcT%d' % i, (self.C, w), torch.float32) for i, w in enumerate(outs)]
         spec += [('bn%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
         spec += [('pair%d' % l, (2, 2 * w), torch.float64) for l, w in enumerate(self.gdim)]
+        spec += [('bnb%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]      # BatchNorm backward sums
         self._gen_gx, gv = _zero_pool(spec, d)
         self.gen.g = gv['g']
         if self.sparse_cond:
             self.dWcT = [gv['dWcT%d' % i] for i in range(len(outs))]
         self._bn_g = [gv['bn%d' % l] for l in range(L)]
         self._bn_pair = [gv['pair%d' % l] for l in range(L)]
+        self._bn_b = [gv['bnb%d' % l] for l in range(L)]
         self._wct_stale = True
         ds, k = [], self.K0
         for i, w in enumerate(self.ddim):
@@ -1105,8 +1107,16 @@ class StepEngine(object):
         # the weight / bias gradients of each layer beside it on the side streams
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
+
+        def bn_back(l):
+            """Descriptor keywords that make the product completing block l's output gradient (the first gdim[l]
+            columns of its result) also take BatchNorm backward's two column sums (fused statistics only)."""
+            if not self.fused_stats or l < 0:
+                return {}
+            blk = slice(self.start[l + 1], self.start[l])
+            return dict(colstat=self._bn_b[l], bn_back=(c.Hg[:, blk], c.Z[l], c.bn_mean[l], c.bn_invstd[l]), splitk=1)
         if hid > 0:
-            self._mm(self.dfake, WL[:, :hid], self.dHg[:, :hid])
+            self._mm(self.dfake, WL[:, :hid], self.dHg[:, :hid], **bn_back(L - 1))
         self._join()     # branches still open from the front half (the hot-id sort, deferred running statistics)
         # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
@@ -1117,18 +1127,22 @@ class StepEngine(object):
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], c.Hg[:, blk]
-            R = ops.colreduce_partial(2, dy, self.part, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
-            R = self._sync_sums(self.part, R, 2 * self.gdim[l])
+            if self.fused_stats:        # the sums came out of the epilogue of the product that completed dy
+                sums, R = self._bn_b[l], 1
+            else:
+                sums = self.part
+                R = ops.colreduce_partial(2, dy, sums, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])
+            R = self._sync_sums(sums, R, 2 * self.gdim[l])
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
             # BatchNorm gradients come from all-reduced column sums, i.e. are global already: written
             # times 1/world so that the sum over ranks of the flat gradient buffer leaves them unchanged
-            ops.bn_relu_bwd_fused(dy, yv, c.Z[l], self.part, R, count, c.bn_mean[l], c.bn_invstd[l],
+            ops.bn_relu_bwd_fused(dy, yv, c.Z[l], sums, R, count, c.bn_mean[l], c.bn_invstd[l],
                                   g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l],
                                   grad_scale=1.0 / self.dist.world if self.dist.active else 1.0)
             Wl = g.P('seq.%d.fc.weight' % l)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
-                self._mm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0)
+                self._mm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0, **bn_back(l - 1))
             if l == 0:
                 # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
                 # bias gradients of every layer (one launch pair) while the product runs beside it

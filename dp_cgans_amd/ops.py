@@ -94,7 +94,9 @@ class GemmDesc(ctypes.Structure):
                 ('gat', ctypes.c_void_p), ('ldg', ctypes.c_int64), ('gidx', ctypes.c_void_p),
                 ('seg_b', ctypes.c_int32), ('seg_c', ctypes.c_int32), ('seg_len', ctypes.c_int32),
                 ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p),
-                ('atomic', ctypes.c_int32)]
+                ('atomic', ctypes.c_int32), ('bn_y', ctypes.c_void_p), ('ld_bn_y', ctypes.c_int64),
+                ('bn_z', ctypes.c_void_p), ('ld_bn_z', ctypes.c_int64), ('bn_mean', ctypes.c_void_p),
+                ('bn_invstd', ctypes.c_void_p), ('stat_n', ctypes.c_int32)]
 
 
 def _addr(t):
@@ -130,7 +132,7 @@ def _mat_strides(t, trans):
 
 def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
               aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
-              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False):
+              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False, bn_back=None):
     """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
     ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
     n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
@@ -172,7 +174,17 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     d.atomic = 1 if atomic else 0
     if colstat is not None:
         _chk(colstat, torch.float64, 'colstat')
-        if colstat.numel() < 2 * N or not colstat.is_contiguous():
+        ncs = N
+        if bn_back is not None:         # (y, z, mean, invstd): BatchNorm-backward sums over the first y.shape[1] columns
+            by, bz, bmean, binv = bn_back
+            for t, nm in ((by, 'bn_y'), (bz, 'bn_z'), (bmean, 'bn_mean'), (binv, 'bn_invstd')):
+                _chk(t, torch.float32, nm)
+            ncs = by.shape[1]
+            if by.shape[0] != M or bz.shape != by.shape or bmean.numel() != ncs or binv.numel() != ncs or ncs > N:
+                raise ValueError('gemm: bn_back = (y [M, F], z [M, F], mean [F], invstd [F]) with F <= N')
+            d.bn_y, d.ld_bn_y, d.bn_z, d.ld_bn_z = _addr(by), _ld(by), _addr(bz), _ld(bz)
+            d.bn_mean, d.bn_invstd, d.stat_n = _addr(bmean), _addr(binv), ncs
+        if colstat.numel() < 2 * ncs or not colstat.is_contiguous():
             raise ValueError('gemm: colstat must be a contiguous fp64 [2, N]')
         d.colstat = _addr(colstat)
         d.splitk = 1

@@ -88,6 +88,11 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
  *   colstat (nullable, fp64 [2][N]) += column sums and column sums of squares of the result (epi 0, no
  *           split-K): BatchNorm1d's batch statistics (dp_cgan.py:75-76) taken in the Linear's epilogue with
  *           fp64 atomics; the caller zeroes it;
+ *   bn_y    (nullable; with colstat, bn_z, bn_mean, bn_invstd, stat_n) the statistics take BatchNorm's BACKWARD form
+ *           over the first stat_n columns of the final result dy (after beta * C): colstat[n] += sum dyh,
+ *           colstat[stat_n + n] += sum dyh * xhat, dyh = dy where the ReLU output bn_y > 0, xhat = (bn_z - mean) *
+ *           invstd - the two column sums of autograd's batch_norm backward (dp_cgan.py:76-77), taken by the product
+ *           that completes the block's output gradient;
  *   atomic  != 0: the product is ADDED to C with fp32 atomics whether or not K is split (beta == 1, plain
  *           product): for products that accumulate into one C concurrently on different streams. */
 typedef struct dpc_gemm_desc {
@@ -109,6 +114,8 @@ typedef struct dpc_gemm_desc {
   int32_t seg_b, seg_c, seg_len, seg_pad; int64_t seg_stride;
   double* colstat;
   int32_t atomic;
+  const float* bn_y; int64_t ld_bn_y; const float* bn_z; int64_t ld_bn_z; const float* bn_mean; const float* bn_invstd;
+  int32_t stat_n;
 } dpc_gemm_desc;
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */

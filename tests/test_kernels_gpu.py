@@ -201,6 +201,45 @@ def test_gemm_segment_maps_run_over_the_data_columns_of_the_pac_row_layout(ops, 
         ops.gemm(Xc[:, :P].contiguous(), torch.zeros(d0, P - 1, device=d_), out, trans_b=True, beta=1.0, seg_b=1, seg=(Dd, P, row))
 
 
+@pytest.mark.parametrize('M,N,K,F', [(512, 256, 128, 256), (200, 100, 37, 100), (8192, 512, 335, 256), (130, 96, 64, 40)])
+def test_gemm_column_statistics_in_the_epilogue(ops, M, N, K, F):
+    """colstat: BatchNorm's forward sums (sum, sum of squares of the result's columns) and, with bn_back, the two
+    backward sums over the first F columns of the accumulated result - against fp64 references and against the
+    separate reduction kernel (dpc_colreduce_partial mode 2)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    C = torch.empty(M, N, device=dev())
+    stat = torch.zeros(2, N, dtype=torch.float64, device=dev())
+    ops.gemm(A.to(dev()), B.to(dev()), C, trans_b=True, bias=bias.to(dev()), colstat=stat)
+    ref = A.double() @ B.double().t() + bias.double()
+    close(C, ref, what='product')
+    close(stat[0], ref.sum(0), what='column sums', scale=float(ref.abs().sum(0).max()))
+    close(stat[1], (ref ** 2).sum(0), what='column sums of squares')
+    # backward form: dy = C0 + A B^T (beta = 1); sums of dyh and dyh * xhat over the first F columns
+    C0 = torch.randn(M, N, generator=g)
+    y = torch.relu(torch.randn(M, F, generator=g))
+    z = torch.randn(M, F, generator=g) * 2 + 0.5
+    mean, invstd = z.mean(0), 1.0 / (z.var(0, unbiased=False) + 1e-5).sqrt()
+    Cd = C0.clone().to(dev())
+    bst = torch.zeros(2, F, dtype=torch.float64, device=dev())
+    yd, zd = y.to(dev()), z.to(dev())
+    ops.gemm(A.to(dev()), B.to(dev()), Cd, trans_b=True, beta=1.0, colstat=bst,
+             bn_back=(yd, zd, mean.to(dev()), invstd.to(dev())))
+    dy = C0.double() + A.double() @ B.double().t()
+    close(Cd, dy, what='accumulated product')
+    dyh = torch.where(y > 0, dy[:, :F], torch.zeros((), dtype=torch.float64))
+    xh = (z.double() - mean.double()) * invstd.double()
+    sc = float(dyh.abs().sum(0).max())
+    close(bst[0], dyh.sum(0), what='sum dyh', scale=sc)
+    close(bst[1], (dyh * xh).sum(0), what='sum dyh xhat', scale=float((dyh * xh).abs().sum(0).max()))
+    part = torch.empty(64 * 2 * F, dtype=torch.float64, device=dev())
+    R = ops.colreduce_partial(2, Cd[:, :F], part, y=yd, z=zd, mean=mean.to(dev()), invstd=invstd.to(dev()))
+    ops.colreduce_fold(part, R, 2 * F)
+    close(bst.view(-1), part[:2 * F], what='epilogue sums vs the reduction kernel', scale=sc, rtol=1e-6)
+
+
 def test_gemm_rejects_bad_arguments(ops):
     A = torch.zeros(4, 4, device=dev())
     with pytest.raises(ValueError):
