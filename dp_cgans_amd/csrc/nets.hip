@@ -137,8 +137,11 @@ __global__ __launch_bounds__(256) void colsum_multi_partial_kernel(MultiColArgs 
   }
   red[rl][c] = s0;
   __syncthreads();
-  if (rl == 0 && f < a.F[p])
-    a.part[a.part0[p] + (int64_t)chunk * a.F[p] + f] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  if (rl == 0 && f < a.F[p]) {
+    const double t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (a.accumulate == 2) atomicAdd(a.out[p] + f, (float)t);       // no finish launch: the chunks meet in out
+    else a.part[a.part0[p] + (int64_t)chunk * a.F[p] + f] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void colsum_multi_finish_kernel(MultiColArgs a) {
@@ -168,9 +171,10 @@ extern "C" int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx
                                 const float* const* w, float* const* out, int accumulate, double* part,
                                 int64_t part_cap, void* stream) {
   DPC_CHECK_ARG(n >= 1 && n <= DPC_MAX_COLSUMS, "colsum_multi: 1..8 sums");
-  DPC_CHECK_ARG(x && ldx && rows && F && w && out && part, "colsum_multi: null pointer");
+  DPC_CHECK_ARG(x && ldx && rows && F && w && out && (part || accumulate == 2), "colsum_multi: null pointer");
+  DPC_CHECK_ARG(accumulate >= 0 && accumulate <= 2, "colsum_multi: accumulate must be 0, 1 or 2");
   MultiColArgs a;
-  a.n = n; a.part = part; a.accumulate = accumulate ? 1 : 0;
+  a.n = n; a.part = part; a.accumulate = accumulate;
   int blk = 0, fin = 0;
   int64_t off = 0;
   for (int p = 0; p < n; ++p) {
@@ -184,10 +188,10 @@ extern "C" int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx
     off += (int64_t)a.R[p] * F[p];
   }
   a.blk0[n] = blk; a.fin0[n] = fin;
-  DPC_CHECK_ARG(off <= part_cap, "colsum_multi: workspace too small");
+  DPC_CHECK_ARG(accumulate == 2 || off <= part_cap, "colsum_multi: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_multi_partial_kernel, dim3((unsigned)blk), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(colsum_multi_finish_kernel, dim3((unsigned)fin), dim3(256), 0, st, a);
+  if (accumulate != 2) hipLaunchKernelGGL(colsum_multi_finish_kernel, dim3((unsigned)fin), dim3(256), 0, st, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -598,7 +598,7 @@ class StepEngine(object):
         L = self.L
         probs = [(self.dZ[l], None, self.gen.G('seq.%d.fc.bias' % l)) for l in range(L)]
         probs.append((self.dfake, None, self.gen.G('seq.%d.bias' % L)))
-        ops.colsum_multi(probs, part)
+        ops.colsum_multi(probs, part, atomic=not self.deterministic)      # (into the zeroed gradient pool)
 
     def _bn_sums(self, c, l, acc):
         """BatchNorm column sums of c.Z[l] for the fused normalisation kernel: -> (workspace, row chunks).  With
@@ -995,7 +995,7 @@ class StepEngine(object):
             probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
             probs.append((self.ones_col, w_last[0:2 * n], d.G('seq.%d.bias' % (3 * M))))
             for i in range(0, len(probs), 8):
-                ops.colsum_multi(probs[i:i + 8], part)
+                ops.colsum_multi(probs[i:i + 8], part, atomic=not self.deterministic)
             if self.sparse_d:
                 # cond columns of dW1: sums of the (clip-scaled) delta rows by hot id, transposed into place below
                 ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,

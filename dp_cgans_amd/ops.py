@@ -440,8 +440,9 @@ def colreduce_fold(part, R, width, nsets=1, set_stride=0, out=None, out_stride=0
                out_stride if out is not None else set_stride, _stream())
 
 
-def colsum_multi(problems, part, accumulate=False):
-    """problems: [(x [rows, F], w [rows] or None, out [F])], up to 8: out = sum_r w[r] x[r, :], two launches in all."""
+def colsum_multi(problems, part, accumulate=False, atomic=False):
+    """problems: [(x [rows, F], w [rows] or None, out [F])], up to 8: out = sum_r w[r] x[r, :], two launches in all;
+    ``atomic``: one launch, the row chunks add into (pre-zeroed / accumulated) out with fp32 atomics."""
     n = len(problems)
     for x, w, out in problems:
         _chk(x, torch.float32, 'x')
@@ -455,8 +456,8 @@ def colsum_multi(problems, part, accumulate=False):
     I32 = ctypes.c_int * n
     lib().call('dpc_colsum_multi', n, P(*[_addr(x) for x, _, _ in problems]), I64(*[_ld(x) for x, _, _ in problems]),
                I64(*[x.shape[0] for x, _, _ in problems]), I32(*[x.shape[1] for x, _, _ in problems]),
-               P(*[_addr(w) for _, w, _ in problems]), P(*[_addr(o) for _, _, o in problems]), int(accumulate), _p(part),
-               part.numel(), _stream())
+               P(*[_addr(w) for _, w, _ in problems]), P(*[_addr(o) for _, _, o in problems]), 2 if atomic else int(accumulate), _p(part),
+               part.numel() if part is not None else 0, _stream())
 
 
 def colsum_noalloc(x, out, w=None, accumulate=False):

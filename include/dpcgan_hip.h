@@ -293,7 +293,9 @@ int dpc_colreduce_fold(const double* part, int R, int width, int nsets, int64_t 
  * the bias gradients and the head layer's weight gradient of one backward pass (autograd of the Linear
  * layers, dp_cgan.py:40,43,75,95).  All array arguments are HOST arrays of n entries, w[p] nullable; part:
  * fp64 workspace of part_cap >= 64 * sum(F) elements.  Bit-identical to dpc_colreduce_partial(mode 1) +
- * dpc_colreduce_finish(kind 1) per sum. */
+ * dpc_colreduce_finish(kind 1) per sum.  accumulate 0: out = sums, 1: out += sums, 2: ONE launch - the row chunks'
+ * fp64 sums are added to out with fp32 atomics (out is accumulated into: the caller zeroes it; part may be NULL;
+ * summation order not fixed). */
 int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
                      const float* const* w, float* const* out, int accumulate, double* part, int64_t part_cap,
                      void* stream);

@@ -240,6 +240,33 @@ def test_gemm_column_statistics_in_the_epilogue(ops, M, N, K, F):
     close(bst.view(-1), part[:2 * F], what='epilogue sums vs the reduction kernel', scale=sc, rtol=1e-6)
 
 
+def test_colsum_multi_all_modes(ops):
+    """dpc_colsum_multi: several weighted column sums in one launch pair (overwrite / accumulate, bit-identical to
+    dpc_colreduce_partial(mode 1) + dpc_colreduce_finish(kind 1) per sum) and in ONE launch with fp32 atomics."""
+    g = torch.Generator().manual_seed(8)
+    shapes = [(3072, 256, True), (2048, 256, False), (3072, 1, True), (100, 37, False), (8192, 335, True)]
+    xs = [torch.randn(r, F, generator=g).to(dev()) for r, F, _ in shapes]
+    ws = [torch.randn(r, generator=g).to(dev()) if w else None for r, F, w in shapes]
+    refs = [((x.double() * (w.double()[:, None] if w is not None else 1.0)).sum(0)).cpu() for x, w in zip(xs, ws)]
+    part = torch.empty(64 * sum(F for _, F, _ in shapes), dtype=torch.float64, device=dev())
+    outs = [torch.full((F,), float('nan'), device=dev()) for _, F, _ in shapes]
+    ops.colsum_multi(list(zip(xs, ws, outs)), part)
+    for o, x, w, r in zip(outs, xs, ws, refs):
+        close(o, r, what='colsum_multi', scale=float((x.double().abs() * (w.double().abs()[:, None] if w is not None else 1.0)).sum(0).max()))
+        single = torch.empty_like(o)
+        R = ops.colreduce_partial(1, x, part, w=w)
+        ops.colreduce_finish(part, R, 1, x.shape[1], 1, single)
+        assert torch.equal(single, o)
+    base = [o.clone() for o in outs]
+    ops.colsum_multi(list(zip(xs, ws, outs)), part, accumulate=True)
+    for o, b in zip(outs, base):
+        assert torch.equal(o, b + b)
+    at = [torch.zeros_like(o) for o in outs]
+    ops.colsum_multi(list(zip(xs, ws, at)), None, atomic=True)
+    for o, x, w, r in zip(at, xs, ws, refs):
+        close(o, r, what='colsum_multi atomic', scale=float((x.double().abs() * (w.double().abs()[:, None] if w is not None else 1.0)).sum(0).max()))
+
+
 def test_gemm_rejects_bad_arguments(ops):
     A = torch.zeros(4, 4, device=dev())
     with pytest.raises(ValueError):
