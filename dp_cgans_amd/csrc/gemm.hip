@@ -69,6 +69,7 @@ struct GemmArgs {
   // block's ReLU output bn_y is positive (else 0) and xhat = (bn_z - mean[n]) * invstd[n]
   const float* bn_y; int64_t ld_bn_y; const float* bn_z; int64_t ld_bn_z; const float* bn_mean; const float* bn_invstd;
   int stat_n;
+  int stat_slots;        // the accumulators are [stat_slots][2][stat_n]: tile row t adds into slot t % stat_slots (fewer atomics per address)
   int force_atomic;      // add the result to C with fp32 atomics even without split-K (another product adds to C meanwhile)
 };
 
@@ -447,8 +448,9 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
       cs0 += __shfl_xor(cs0, 32, 64);
       cs1 += __shfl_xor(cs1, 32, 64);
       if (lk == 0 && live && col < g.stat_n) {
-        atomicAdd(g.colstat + col, (double)cs0);
-        atomicAdd(g.colstat + g.stat_n + col, (double)cs1);
+        double* cs = g.colstat + (int64_t)((m0 / BM) % g.stat_slots) * 2 * g.stat_n;
+        atomicAdd(cs + col, (double)cs0);
+        atomicAdd(cs + g.stat_n + col, (double)cs1);
       }
     }
   };
@@ -683,6 +685,8 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   g.colstat = d.colstat;
   g.bn_y = d.bn_y; g.ld_bn_y = d.ld_bn_y; g.bn_z = d.bn_z; g.ld_bn_z = d.ld_bn_z; g.bn_mean = d.bn_mean; g.bn_invstd = d.bn_invstd;
   g.stat_n = d.bn_y ? d.stat_n : N;
+  g.stat_slots = d.stat_slots > 1 ? d.stat_slots : 1;
+  DPC_CHECK_ARG(d.stat_slots >= 0 && d.stat_slots <= 64, "gemm: stat_slots must be 0..64");
   DPC_CHECK_ARG(!d.bn_y || (d.colstat && d.bn_z && d.bn_mean && d.bn_invstd && d.stat_n >= 1 && d.stat_n <= N &&
                             d.ld_bn_y >= d.stat_n && d.ld_bn_z >= d.stat_n && (beta == 0.f || beta == 1.f)),
                 "gemm: BatchNorm-backward statistics need colstat, y, z, mean, invstd and 1 <= stat_n <= N");

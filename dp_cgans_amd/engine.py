@@ -244,6 +244,9 @@ class StepEngine(object):
         # BatchNorm's column sums are taken in the Linear's GEMM epilogue (fp64 atomics into [2, F] accumulators:
         # GemmArgs::colstat) unless the engine runs in reproducible mode (separate fixed-order reduction)
         self.fused_stats = not self.deterministic
+        # their accumulators are SLOTS x [2, F]: tile row t adds into slot t % SLOTS (128 tile rows meeting at one fp64
+        # address cost a product 4-5 us), and the normalisation kernels sum the slots like row-chunk partials
+        self.stat_slots = int(os.environ.get('DPCGAN_STAT_SLOTS', '4')) if self.fused_stats else 1
         # Everything the generator update accumulates into lies in ONE buffer that one fill zeroes (_g_front):
         # the flat gradient (split-K products add with beta = 1), the transposed cond-column gradients, the
         # BatchNorm statistics accumulators of the update's forward (and of both forwards of a data-parallel
@@ -251,9 +254,10 @@ class StepEngine(object):
         spec = [('g', (self.gen.n,), torch.float32)]
         if self.sparse_cond:
             spec += [('dWcT%d' % i, (self.C, w), torch.float32) for i, w in enumerate(outs)]
-        spec += [('bn%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
-        spec += [('pair%d' % l, (2, 2 * w), torch.float64) for l, w in enumerate(self.gdim)]
-        spec += [('bnb%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]      # BatchNorm backward sums
+        S = self.stat_slots
+        spec += [('bn%d' % l, (S * 2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
+        spec += [('pair%d' % l, (2, S * 2 * w), torch.float64) for l, w in enumerate(self.gdim)]
+        spec += [('bnb%d' % l, (S * 2 * w,), torch.float64) for l, w in enumerate(self.gdim)]      # BatchNorm backward sums
         self._gen_gx, gv = _zero_pool(spec, d)
         self.gen.g = gv['g']
         if self.sparse_cond:
@@ -358,7 +362,7 @@ class StepEngine(object):
         spec = [('g', (self.disc.n,), torch.float32), ('P1', (d0, d0), torch.float32), ('G1', (d0, d0), torch.float32)]
         if self.sparse_d:
             spec.append(('dW1cT', (pac * self.C, ldw), torch.float32))
-        spec += [('bn%d' % l, (2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
+        spec += [('bn%d' % l, (self.stat_slots * 2 * w,), torch.float64) for l, w in enumerate(self.gdim)]
         self._disc_gx, dv = _zero_pool(spec, d)
         self.disc.g = dv['g']
         self._bn_d = [dv['bn%d' % l] for l in range(L)]
@@ -569,17 +573,18 @@ class StepEngine(object):
         self._wct_stale = False
 
     def _gen_linear(self, c, l, out, bias, colstat=None):
-        """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear); ``colstat``: fp64 [2, F] accumulator
-        that receives the column sums / sums of squares of ``out`` in the same launch (BatchNorm statistics)."""
+        """out = Hg[:, start[l]:] W_l^T + bias (layer L = the output Linear); ``colstat``: fp64 [stat_slots, 2, F]
+        accumulator that receives the column sums / sums of squares of ``out`` in the same launch (BatchNorm statistics)."""
         W = self._gen_weight(l)
+        st = dict(colstat=colstat, stat_slots=self.stat_slots) if colstat is not None else {}
         if not self.sparse_cond:
-            self._mm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias, colstat=colstat)
+            self._mm(c.Hg[:, self.start[l]:], W, out, trans_b=True, bias=bias, **st)
             return
         if self._wct_stale or self.gen.loaded:       # parameters were (re)loaded outside an optimiser step
             self.gen.loaded = False
             self._refresh_wct()
         self._mm_gather(c.Hg[:, self.start[l]:self.Wtot - self.C], W[:, :W.shape[1] - self.C], out, self.WcT[l], c.sel,
-                        bias=bias, colstat=colstat)
+                        bias=bias, **st)
 
     def _gen_dweight(self, c, l, dy, what=3):
         """dW_l (+)= dy^T Hg[:, start[l]:] into the zeroed gradient buffer (``what`` & 1: the product over the
@@ -604,7 +609,7 @@ class StepEngine(object):
         """BatchNorm column sums of c.Z[l] for the fused normalisation kernel: -> (workspace, row chunks).  With
         fused statistics the Linear's epilogue has left the finished [2, F] sums in ``acc`` already."""
         if self.fused_stats:
-            return acc, 1
+            return acc, self.stat_slots
         R = ops.colreduce_partial(0, c.Z[l], c.part[l])
         return c.part[l], R
 
@@ -660,9 +665,10 @@ class StepEngine(object):
             F = self.gdim[l]
             b = g.P('seq.%d.fc.bias' % l)
             if self.fused_stats:
-                acc = self._bn_pair[l]              # [2 contexts][2F] finished sums (zeroed with the gradient pool)
-                R, width = 1, 2 * F
+                acc = self._bn_pair[l]              # [2 contexts][slots, 2F] sums (zeroed with the gradient pool)
+                R, width = self.stat_slots, self.stat_slots * 2 * F
                 sums = [acc[0], acc[1]]
+                fold = self.pair_fold[:4 * F]
             else:
                 R = ops.colreduce_rows(self.B, F)
                 width = R * 2 * F
@@ -677,12 +683,14 @@ class StepEngine(object):
                 assert ops.colreduce_partial(0, ca.Z[l], sums[0]) == R
             if lanes:
                 main.wait_stream(self.early)
-            if self.fused_stats:
-                self._allreduce(self._bn_pair[l].view(-1))
-            else:               # both contexts' partials folded to [2][2F] finished sums: one small all-reduce
-                ops.colreduce_fold(self.pair_part, R, 2 * F, nsets=2, set_stride=width, out=fold, out_stride=2 * F)
+            # both contexts' slots / row-chunk partials folded to [2][2F] finished sums: one small all-reduce
+            src = self._bn_pair[l].view(-1) if self.fused_stats else self.pair_part
+            if R > 1:
+                ops.colreduce_fold(src, R, 2 * F, nsets=2, set_stride=width, out=fold, out_stride=2 * F)
                 self._allreduce(fold)
                 sums, R = [fold[0:2 * F], fold[2 * F:4 * F]], 1
+            else:
+                self._allreduce(src[:2 * width])
             for i, c in enumerate((ca, cb)):
                 if i == 1 and lanes:
                     self.early.wait_stream(main)     # after ca's: the running statistics are updated in sequence order
@@ -1114,7 +1122,8 @@ class StepEngine(object):
             if not self.fused_stats or l < 0:
                 return {}
             blk = slice(self.start[l + 1], self.start[l])
-            return dict(colstat=self._bn_b[l], bn_back=(c.Hg[:, blk], c.Z[l], c.bn_mean[l], c.bn_invstd[l]), splitk=1)
+            return dict(colstat=self._bn_b[l], stat_slots=self.stat_slots,
+                        bn_back=(c.Hg[:, blk], c.Z[l], c.bn_mean[l], c.bn_invstd[l]), splitk=1)
         if hid > 0:
             self._mm(self.dfake, WL[:, :hid], self.dHg[:, :hid], **bn_back(L - 1))
         self._join()     # branches still open from the front half (the hot-id sort, deferred running statistics)
@@ -1128,7 +1137,7 @@ class StepEngine(object):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], c.Hg[:, blk]
             if self.fused_stats:        # the sums came out of the epilogue of the product that completed dy
-                sums, R = self._bn_b[l], 1
+                sums, R = self._bn_b[l], self.stat_slots
             else:
                 sums = self.part
                 R = ops.colreduce_partial(2, dy, sums, y=yv, z=c.Z[l], mean=c.bn_mean[l], invstd=c.bn_invstd[l])

@@ -96,7 +96,7 @@ class GemmDesc(ctypes.Structure):
                 ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p),
                 ('atomic', ctypes.c_int32), ('bn_y', ctypes.c_void_p), ('ld_bn_y', ctypes.c_int64),
                 ('bn_z', ctypes.c_void_p), ('ld_bn_z', ctypes.c_int64), ('bn_mean', ctypes.c_void_p),
-                ('bn_invstd', ctypes.c_void_p), ('stat_n', ctypes.c_int32)]
+                ('bn_invstd', ctypes.c_void_p), ('stat_n', ctypes.c_int32), ('stat_slots', ctypes.c_int32)]
 
 
 def _addr(t):
@@ -132,7 +132,7 @@ def _mat_strides(t, trans):
 
 def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
               aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
-              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False, bn_back=None):
+              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False, bn_back=None, stat_slots=1):
     """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
     ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
     n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
@@ -184,9 +184,10 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
                 raise ValueError('gemm: bn_back = (y [M, F], z [M, F], mean [F], invstd [F]) with F <= N')
             d.bn_y, d.ld_bn_y, d.bn_z, d.ld_bn_z = _addr(by), _ld(by), _addr(bz), _ld(bz)
             d.bn_mean, d.bn_invstd, d.stat_n = _addr(bmean), _addr(binv), ncs
-        if colstat.numel() < 2 * ncs or not colstat.is_contiguous():
-            raise ValueError('gemm: colstat must be a contiguous fp64 [2, N]')
+        if colstat.numel() < 2 * ncs * max(1, int(stat_slots)) or not colstat.is_contiguous():
+            raise ValueError('gemm: colstat must be a contiguous fp64 [stat_slots, 2, N]')
         d.colstat = _addr(colstat)
+        d.stat_slots = int(stat_slots)
         d.splitk = 1
     if seg is not None:
         d.seg_b, d.seg_c = int(seg_b), int(seg_c)
@@ -217,10 +218,11 @@ def gemm(A, B, C, **kw):
     return C
 
 
-def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE, splitk=None, colstat=None):
+def gemm_gather(A, B, C, gat, gidx, trans_b=True, bias=None, epi=EPI_NONE, splitk=None, colstat=None, stat_slots=1):
     """C = epi(A @ op(B) + bias + gat[gidx[:,0]] + gat[gidx[:,1]]) (ids < 0 skipped): Linear over the dense
     columns of an input whose trailing cond columns are one-/two-hot; gat = W[:, cond columns]^T."""
-    gemm_run([gemm_desc(A, B, C, trans_b=trans_b, bias=bias, epi=epi, gat=gat, gidx=gidx, splitk=splitk, colstat=colstat)])
+    gemm_run([gemm_desc(A, B, C, trans_b=trans_b, bias=bias, epi=epi, gat=gat, gidx=gidx, splitk=splitk, colstat=colstat,
+                        stat_slots=stat_slots)])
     return C
 
 

@@ -87,7 +87,9 @@ int dpc_gemm_f32_gather(int M, int N, int K, float alpha, const float* A, int64_
  *           layout, beta == 1; columns beyond seg_len of a segment are not stored);
  *   colstat (nullable, fp64 [2][N]) += column sums and column sums of squares of the result (epi 0, no
  *           split-K): BatchNorm1d's batch statistics (dp_cgan.py:75-76) taken in the Linear's epilogue with
- *           fp64 atomics; the caller zeroes it;
+ *           fp64 atomics; the caller zeroes it.  stat_slots S > 1: colstat is [S][2][N] and the tiles of tile row t add
+ *           into slot t mod S (S-fold fewer atomics per address); the consumer sums the S slots (they have the layout
+ *           of dpc_colreduce_partial's row-chunk partials: dpc_bn_relu_*_fused / dpc_colreduce_fold take them as R = S);
  *   bn_y    (nullable; with colstat, bn_z, bn_mean, bn_invstd, stat_n) the statistics take BatchNorm's BACKWARD form
  *           over the first stat_n columns of the final result dy (after beta * C): colstat[n] += sum dyh,
  *           colstat[stat_n + n] += sum dyh * xhat, dyh = dy where the ReLU output bn_y > 0, xhat = (bn_z - mean) *
@@ -116,6 +118,7 @@ typedef struct dpc_gemm_desc {
   int32_t atomic;
   const float* bn_y; int64_t ld_bn_y; const float* bn_z; int64_t ld_bn_z; const float* bn_mean; const float* bn_invstd;
   int32_t stat_n;
+  int32_t stat_slots;
 } dpc_gemm_desc;
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */

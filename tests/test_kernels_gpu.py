@@ -217,6 +217,12 @@ def test_gemm_column_statistics_in_the_epilogue(ops, M, N, K, F):
     close(C, ref, what='product')
     close(stat[0], ref.sum(0), what='column sums', scale=float(ref.abs().sum(0).max()))
     close(stat[1], (ref ** 2).sum(0), what='column sums of squares')
+    # slots: tile row t adds into slot t % 4; the slots sum to the same statistics
+    st4 = torch.zeros(4, 2, N, dtype=torch.float64, device=dev())
+    ops.gemm(A.to(dev()), B.to(dev()), C, trans_b=True, bias=bias.to(dev()), colstat=st4, stat_slots=4)
+    close(st4.sum(0)[0], ref.sum(0), what='slotted column sums', scale=float(ref.abs().sum(0).max()))
+    close(st4.sum(0)[1], (ref ** 2).sum(0), what='slotted column sums of squares')
+    assert M <= 64 or float(st4[1].abs().max()) > 0
     # backward form: dy = C0 + A B^T (beta = 1); sums of dyh and dyh * xhat over the first F columns
     C0 = torch.randn(M, N, generator=g)
     y = torch.relu(torch.randn(M, F, generator=g))
