@@ -133,12 +133,16 @@ def _both_forms_agree(span, s, gdim, ddim, mode, clip=0.05):
     other, which moves the gradients by ~1e-3 - between ANY two fp32 implementations, the reference on two BLAS
     builds included.  At the widest configs (10^7 pre-activations per update) a batch holds one or two such
     ties.  They show up as differing stored slopes; the comparison then drops exactly those units (their Dropout
-    keep bit, injected here, is cleared: slope 0 in both forms) and runs again."""
+    keep bit, injected here, is cleared: slope 0 in both forms) and runs again.  The generator's ReLU has the same
+    jump: a hidden unit whose normalised pre-activation lies within rounding of 0 is "on" in one form and "off" in
+    the other (seen as differing signs of the stored activations); the latent vector of such a row of the
+    generator update (injected here too) is redrawn."""
     from dp_cgans_amd.engine import StepEngine
     g = torch.Generator(device=DEV).manual_seed(5)
     n = 8192 // 8
     keeps_d = [(torch.rand(3 * n, w, device=DEV, generator=g) < 0.5).to(torch.uint8) for w in ddim]
     keeps_g = [(torch.rand(n, w, device=DEV, generator=g) < 0.5).to(torch.uint8) for w in ddim]
+    zg = torch.randn(8192, 128, device=DEV, generator=g)
 
     def run(**kw):
         eng = StepEngine(span, 128, gdim, ddim, 8192, 8, DEV, private=True, dp_mode=mode, dp_clip=clip, seed=11, **kw)
@@ -147,17 +151,18 @@ def _both_forms_agree(span, s, gdim, ddim, mode, clip=0.05):
         eng.slopes_d = [x.clone() for x in eng.S]
         dg = eng.disc.g.clone()
         norms = eng.norms.clone()
-        eng.g_step(inj={'keep': keeps_g}, update=False)
+        eng.g_step(inj={'keep': keeps_g, 'z': zg}, update=False)
         eng.slopes_g = [x[0:n].clone() for x in eng.S]
+        eng.relu_on = eng.cg.Hg[:, :eng.start[0]] > 0
         torch.cuda.synchronize()
         return eng, dg, norms, eng.gen.g.clone(), eng.losses.clone()
 
-    def close(x, y, what, rtol=2e-5):
-        err = float((x.double() - y.double()).abs().max()) / max(float(y.double().abs().max()), 1e-30)
+    def close(x, y, what, rtol=2e-5, scale=None):
+        err = float((x.double() - y.double()).abs().max()) / (scale or max(float(y.double().abs().max()), 1e-30))
         assert err <= rtol, '%s: %.3e' % (what, err)
 
     dropped = 0
-    for attempt in range(6):
+    for attempt in range(8):
         a, dga, na, gga, la = run()
         b, dgb, nb, ggb, lb = run(gp_gram=False, sparse_cond=False)
         assert a.gp_gram and a.sparse_cond and a.sparse_d and not b.gp_gram and not b.sparse_cond and not b.sparse_d
@@ -168,13 +173,20 @@ def _both_forms_agree(span, s, gdim, ddim, mode, clip=0.05):
                 flip = sa != sb
                 ties += int(flip.sum())
                 k[flip] = 0
-        assert ties <= 8, 'slopes differ in %d places: not rounding ties' % ties
+        rows = (a.relu_on != b.relu_on).any(1).nonzero().flatten()
+        assert ties <= 8 and rows.numel() <= 8, 'slopes differ in %d places, ReLU states in %d rows: not rounding ties' % (ties, rows.numel())
+        if rows.numel():
+            zg[rows] = torch.randn(rows.numel(), 128, device=DEV, generator=g)
+            ties += int(rows.numel())
         close(la, lb, 'losses')
         if ties:
             dropped += ties
             continue
+        head_bias = a.disc.keys[-1]
         for k in a.disc.keys:
-            close(a.disc.view(dga, k), b.disc.view(dgb, k), 'D grad ' + k)
+            # the head's bias gradient is sum_i (+w_i - w_i) over the fake and real rows: exactly 0 in real arithmetic,
+            # rounding residue of either summation order in fp32 - held to the bar relative to sum |terms| = 2
+            close(a.disc.view(dga, k), b.disc.view(dgb, k), 'D grad ' + k, scale=2.0 if k == head_bias else None)
         for k in a.gen.keys:
             if 'fc.bias' in k:        # exactly-zero gradient in front of BatchNorm: rounding noise on both sides
                 continue
@@ -182,7 +194,7 @@ def _both_forms_agree(span, s, gdim, ddim, mode, clip=0.05):
         if mode == 'dpsgd':
             close(na, nb, 'per-example norms')
             assert float(a.rowc.min()) < 1.0
-        print('LeakyReLU ties dropped: %d' % dropped)
+        print('LeakyReLU / ReLU ties dropped: %d' % dropped)
         return
     pytest.fail('ties kept appearing')
 
