@@ -148,6 +148,13 @@ def trace_figures(args):
     rec = json.load(open(path))
     if rec.get('source_sha') != source_sha():
         return None
+    # the same step traced as ONE chain (bench.py --serial): its kernels never overlap, so their durations are the
+    # kernels' own - the trace figure that the live chain replay below has to agree with
+    spath = os.path.join(ROOT, 'profiles', 'r02_kernel_roofline_serial.json')
+    if os.path.exists(spath):
+        srec = json.load(open(spath))
+        if srec.get('source_sha') == source_sha():
+            rec['serial'] = srec
     return rec
 
 
@@ -225,6 +232,12 @@ def step_kernel_rooflines(eng, eager_step, args):
             'source': 'profiles/%s (rocprofv3 --kernel-trace --stats of this command: the launches inside the '
                       'replayed step graph, beside its side branches)' % trace['stats_csv']},
     }
+    ts = (trace or {}).get('serial', {}).get('kernels', {}).get('gemm')
+    if ts:
+        res['roofline']['serial_graph_trace'] = {
+            'achieved': ts['achieved'], 'frac': ts['frac'], 'avg_launch_us': ts['avg_us'],
+            'source': 'profiles/%s (the same command with --serial: the step graph as one chain, no kernel beside '
+                      'the products)' % trace['serial']['stats_csv']}
     # ---- the DP kernels as the step runs them (HBM-bound; at this size their buffers sit in the 256 MB
     # Infinity Cache / L2, and n = B / pac examples do not fill the chip: latency, not bandwidth, bounds them)
     n, M = eng.n, eng.M

@@ -75,6 +75,7 @@ def main():
     ap.add_argument('--write')
     ap.add_argument('--mfma', help='counter_collection.csv of the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass')
     ap.add_argument('--out', required=True)
+    ap.add_argument('--command', default='rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline')
     a = ap.parse_args()
 
     line = [l for l in open(a.bench) if l.startswith('{')][-1]
@@ -150,7 +151,7 @@ def main():
                          'SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 2 '
                          '--no-cpu-baseline --no-roofline --no-graph (launches serialised by the counter collection)')
     out = {
-        'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline',
+        'command': a.command,
         'workload': cfg['workload'], 'source_sha': source_sha(), 'stats_csv': a.stats_name,
         'steps_averaged': steps, 'step_us_in_trace': span_us / steps, 'bench_ms_per_step_under_rocprof': bench['ms_per_step'],
         'kernel_us_per_step': sum(v['us_per_step'] for v in kernels.values()),

@@ -14,3 +14,8 @@ python tools/kernel_roofline.py --trace $P/trace/bench_kernel_trace.csv --bench 
   --stats-name ${tag}_bench_T1M_kernel_stats.csv --fetch $P/pmc_FETCH_SIZE/pmc_counter_collection.csv \
   --write $P/pmc_WRITE_SIZE/pmc_counter_collection.csv --mfma $P/pmc_MFMA/pmc_counter_collection.csv \
   --out profiles/${tag}_kernel_roofline.json
+cp $P/trace_serial/bench_kernel_stats.csv profiles/${tag}_bench_T1M_serial_kernel_stats.csv
+cp $P/bench_serial_under_rocprof.json.log profiles/${tag}_bench_T1M_serial_under_rocprof.json.log
+python tools/kernel_roofline.py --trace $P/trace_serial/bench_kernel_trace.csv --bench $P/bench_serial_under_rocprof.json.log \
+  --stats-name ${tag}_bench_T1M_serial_kernel_stats.csv --out profiles/${tag}_kernel_roofline_serial.json \
+  --command 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --serial --no-cpu-baseline' > /dev/null

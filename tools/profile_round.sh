@@ -8,6 +8,8 @@ out=gpurun_out/${tag}prof
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out" && mkdir -p "$out"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json.log" 2> "$out/trace.err"
+# the same step as ONE chain (--serial: no side branches, kernels never overlap): per-kernel durations without co-runners
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_serial" -o bench -- python3 bench.py --serial --no-cpu-baseline > "$out/bench_serial_under_rocprof.json.log" 2> "$out/trace_serial.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -o pmc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > "$out/pmc_$c.json.log" 2> "$out/pmc_$c.err"
 done
