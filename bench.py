@@ -218,8 +218,8 @@ def step_kernel_rooflines(eng, eager_step, args):
         'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
         'traffic': tg['traffic_bytes_per_launch'] if tg else None,
-        'traffic_unit': 'HBM bytes per launch (TCC_EA0_RDREQ/WRREQ passes of this command, gfx950 correction; '
-                        'tools/pmc_traffic.py)',
+        'traffic_unit': 'HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of this workload: '
+                        'tools/profile_round.sh, tools/kernel_roofline.py)',
         'algorithmic_bytes_per_launch': alg_bytes,
         'kernel': 'gemm_f32_kernel + gemm_ksplit_kernel (all tile variants)', 'launches_per_step': nlaunch,
         'gflop_per_launch': flops / nlaunch / 1e9, 'avg_launch_us': us / nlaunch,

@@ -25,7 +25,7 @@ def per_kernel(path):
 
 def main():
     F, W = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-    is_gemm = lambda k: 'gemm_f32_kernel' in k
+    is_gemm = lambda k: 'gemm_f32_kernel' in k or 'gemm_ksplit_kernel' in k
     gf = [v for k, vs in F.items() if is_gemm(k) for v in vs]
     gw = [v for k, vs in W.items() if is_gemm(k) for v in vs]
     cal = [v for k, vs in F.items() if 'activate_fwd_kernel' in k for v in vs]
