@@ -247,6 +247,10 @@ class StepEngine(object):
         # their accumulators are SLOTS x [2, F]: tile row t adds into slot t % SLOTS (128 tile rows meeting at one fp64
         # address cost a product 4-5 us), and the normalisation kernels sum the slots like row-chunk partials
         self.stat_slots = int(os.environ.get('DPCGAN_STAT_SLOTS', '4')) if self.fused_stats else 1
+        # BatchNorm backward's sums come out of the epilogue of the product that completes the block's output gradient -
+        # for blocks up to this width (measured: 0.875 -> 0.852 ms per step at width 256, but 5.21 -> 5.37 ms at width
+        # 1024, where the epilogue's extra y / z tile reads outweigh the two reduction launches they replace)
+        self.bnb_max_width = 512
         # Everything the generator update accumulates into lies in ONE buffer that one fill zeroes (_g_front):
         # the flat gradient (split-K products add with beta = 1), the transposed cond-column gradients, the
         # BatchNorm statistics accumulators of the update's forward (and of both forwards of a data-parallel
@@ -1116,10 +1120,13 @@ class StepEngine(object):
         hid = self.start[0]                                    # columns that hold hidden activations
         WL = g.P('seq.%d.weight' % L)
 
+        def fused_bnb(l):
+            return self.fused_stats and self.gdim[l] <= self.bnb_max_width
+
         def bn_back(l):
             """Descriptor keywords that make the product completing block l's output gradient (the first gdim[l]
             columns of its result) also take BatchNorm backward's two column sums (fused statistics only)."""
-            if not self.fused_stats or l < 0:
+            if l < 0 or not fused_bnb(l):
                 return {}
             blk = slice(self.start[l + 1], self.start[l])
             return dict(colstat=self._bn_b[l], stat_slots=self.stat_slots,
@@ -1136,7 +1143,7 @@ class StepEngine(object):
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], c.Hg[:, blk]
-            if self.fused_stats:        # the sums came out of the epilogue of the product that completed dy
+            if fused_bnb(l):            # the sums came out of the epilogue of the product that completed dy
                 sums, R = self._bn_b[l], self.stat_slots
             else:
                 sums = self.part
