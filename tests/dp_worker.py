@@ -119,6 +119,53 @@ def graph(dist, dev, mode):
     assert torch.isfinite(a.gen.p).all()
 
 
+def fused(dist, dev, mode):
+    """The default (non-reproducible) data-parallel step: BatchNorm sums out of the GEMM epilogues in slots, folded on
+    the device and all-reduced as one vector per layer, the two generator forwards paired - against the same step
+    with separate forwards and (one rank) against the engine without any collective.  One training step from
+    identical parameters and draws; the gradient buffers it leaves behind within the step's 2e-5 bar."""
+    import copy
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+
+    def make(d):
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=d)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=9 + dist.rank)
+        return eng
+    a, b, g = make(dist), make(dist), make(dist)
+    assert a.fused_stats and a.stat_slots > 1
+    b.pair_forwards = False
+    a.train_step(1)
+    b.train_step(1)
+    gs = GraphStep(g, d_steps=1)
+    gs.run()
+    engines = [('separate forwards', b), ('graph step (first run: eager)', g)]
+    if dist.world == 1:
+        off = copy.copy(dist)
+        off.active = False
+        q = make(off)
+        q.train_step(1)
+        engines.append(('no collectives', q))
+    torch.cuda.synchronize()
+
+    def close(x, y, what):
+        err = float((x.double() - y.double()).abs().max()) / max(float(y.double().abs().max()), 1e-30)
+        assert err <= 2e-5, '%s: %.3e' % (what, err)
+    for name, e in engines:
+        for k in a.disc.keys[:-1]:          # (the head bias gradient is an exact zero + rounding residue)
+            close(a.disc.G(k), e.disc.G(k), '%s: D grad %s' % (name, k))
+        for k in a.gen.keys:
+            if 'fc.bias' not in k:
+                close(a.gen.G(k), e.gen.G(k), '%s: G grad %s' % (name, k))
+        sa, se = a.generator_state_dict(), e.generator_state_dict()
+        for k in sa:
+            if 'running' in k:
+                close(sa[k], se[k], '%s: %s' % (name, k))
+
+
 def main():
     mode = sys.argv[1]
     from dp_cgans_amd.parallel import Dist
@@ -127,6 +174,8 @@ def main():
     torch.cuda.set_device(dev)
     if mode == 'replay':
         replay(dist, dev)
+    elif mode == 'fused':
+        fused(dist, dev, sys.argv[2])
     else:
         graph(dist, dev, sys.argv[2])
     dist.barrier()

@@ -68,3 +68,14 @@ def test_rccl_single_rank_graph_replay_equals_eager(mode, collectives):
     keeps them eager between graph segments (the fallback).  Both bit-equal to the eager step."""
     env = dict(RCCL1, DPCGAN_GRAPH_COLLECTIVES='1' if collectives == 'in-graph' else '0')
     launch(['graph', mode], world=1, extra_env=env)
+
+
+@pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
+def test_rccl_single_rank_default_step_with_fused_statistics(mode):
+    """The default data-parallel step (statistics from the GEMM epilogues, folded slots, paired forwards) over RCCL."""
+    launch(['fused', mode], world=1, extra_env=RCCL1)
+
+
+@pytest.mark.parametrize('mode', ['dpsgd'])
+def test_two_ranks_default_step_with_fused_statistics(mode):
+    launch(['fused', mode])
