@@ -468,8 +468,13 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
 // tiles used to fetch its 60 MB activation operand once per tile row: 2x the algorithmic HBM/MALL
 // traffic by FETCH_SIZE).
 __device__ __forceinline__ void gemm_tile_coords(const GemmArgs& g, int wg, int& tile_m, int& tile_n) {
-  if (g.tiles_m < g.tiles_n) { tile_n = wg / g.tiles_m; tile_m = wg - tile_n * g.tiles_m; }
-  else { tile_m = wg / g.tiles_n; tile_n = wg - tile_m * g.tiles_n; }
+  // (selects, not two branches writing through the references: hipcc turned those into a store + load of the pair
+  // through scratch memory at the top of every product - a dependent memory round trip before the first operand load)
+  const bool m_inner = g.tiles_m < g.tiles_n;
+  const int inner = m_inner ? g.tiles_m : g.tiles_n;
+  const int q = wg / inner, r = wg - q * inner;
+  tile_m = m_inner ? r : q;
+  tile_n = m_inner ? q : r;
 }
 
 // Slot of block `bid` among `n` blocks such that the blocks of one XCD (ids congruent mod 8) hold a

@@ -756,18 +756,31 @@ struct FirstActArgs {
                     // the per-example Gram kernel, which needs x W1^T over ALL columns)
 };
 
-// sum over a row's pac sub-rows of the (up to two) hot rows of gat, 4 consecutive columns from j
+// sum over a row's pac sub-rows of the (up to two) hot rows of gat, 4 consecutive columns from j.  Branch-free
+// and four sub-rows at a time: the 8 ids of a group are loaded together, then the 8 rows of gat (an absent id
+// reads row 0 and adds +0) - with a branch around every load the 2 x pac loads of a row went one L2 round trip
+// after the other.  Same summation order as the plain loop (sub-row, then hot id).
 __device__ __forceinline__ float4 first_act_gather4(const FirstActArgs& a, const int32_t* __restrict__ sel, int64_t r, int j) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const int32_t* ids = sel + r * a.pac * 2;
-  for (int s = 0; s < a.pac; ++s) {
+  for (int s0 = 0; s0 < a.pac; s0 += 4) {
+    int id[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int id = ids[2 * s + h];
-      if (id >= 0) {
-        const float4 w = *reinterpret_cast<const float4*>(a.gat + ((int64_t)s * a.C + id) * a.ldg + j);
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-      }
+    for (int q = 0; q < 8; ++q) {
+      const int s = min(s0 + (q >> 1), a.pac - 1);
+      id[q] = ids[2 * s + (q & 1)];
+      if (s0 + (q >> 1) >= a.pac) id[q] = -1;
+    }
+    float4 w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int s = min(s0 + (q >> 1), a.pac - 1);
+      w[q] = *reinterpret_cast<const float4*>(a.gat + ((int64_t)s * a.C + max(id[q], 0)) * a.ldg + j);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool on = id[q] >= 0;
+      v.x += on ? w[q].x : 0.f; v.y += on ? w[q].y : 0.f; v.z += on ? w[q].z : 0.f; v.w += on ? w[q].w : 0.f;
     }
   }
   return v;
@@ -838,10 +851,9 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
         }
       }
     }
-    const int np = a.stacked ? 3 : 1;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      if (p >= np) break;
+    // (one call per stacked block, no unrolled loop with an early exit over arrays picked by the block index:
+    // hipcc kept those in scratch memory - a store, a drained load queue and a load in every iteration)
+    auto emit = [&](const int p, const float (&z)[W]) {
       const int64_t row = (int64_t)p * a.n + r;
       uint32_t bits[W];
       if (a.keep) {
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
       float h[W], s[W];
 #pragma unroll
       for (int e = 0; e < W; ++e) {
-        const float pre = (p == 0 ? zf[e] : (p == 1 ? zr[e] : al * zr[e] + (1.f - al) * zf[e])) + b[e];
+        const float pre = z[e] + b[e];
         s[e] = (pre > 0.f ? 1.f : a.leak) * ((bits[e] >> 31) ? 2.f : 0.f);
         h[e] = pre * s[e];
       }
@@ -868,6 +880,14 @@ __global__ __launch_bounds__(256) void disc_first_act_kernel(FirstActArgs a) {
         a.H[row * a.ldh + j] = h[0];
         a.S[row * a.lds + j] = s[0];
       }
+    };
+    emit(0, zf);
+    if (a.stacked) {
+      emit(1, zr);
+      float zi[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) zi[e] = al * zr[e] + (1.f - al) * zf[e];
+      emit(2, zi);
     }
   }
 }
