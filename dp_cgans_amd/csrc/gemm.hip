@@ -279,21 +279,29 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   // K loop of the generator's first layer (K = 128).
   const bool gather = (g.gat != nullptr) && !atomic;
   constexpr int GV = BN / 4;
-  constexpr bool GPRE = (BM * BN <= 4096);
+  // (only the forward form x W^T, both operands k-contiguous, ever carries a gather: the other variants do not pay the registers)
+  constexpr bool GPRE = (BM * BN <= 4096) && A_KC && B_KC;
   constexpr int GQ = GPRE ? (BM * GV) / 256 : 1;
   const bool gvec = gather && ((g.ldg & 3) == 0) && (((uintptr_t)g.gat & 15) == 0) && (n0 + BN <= g.N);
-  f32x4 gv[GQ];
+  // Branch-free: all ids first, then all rows (an absent id reads row 0 and is dropped by a select after the
+  // K loop).  With `if (id >= 0) v += load` hipcc branched around every load and drained the load queue at each
+  // join: 3 x GQ dependent L2 round trips in front of the K loop of every gather product.
+  f32x4 gw0[GQ], gw1[GQ];
+  int gi0[GQ], gi1[GQ];
   if (GPRE && gvec) {
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
       const int idx = threadIdx.x + q * 256;
+      const int row = min(m0 + idx / GV, g.M - 1);
+      gi0[q] = g.gidx[2 * row];
+      gi1[q] = g.gidx[2 * row + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      const int idx = threadIdx.x + q * 256;
       const int r = idx / GV, c4 = (idx - r * GV) * 4;
-      const int row = min(m0 + r, g.M - 1);
-      const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
-      if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
-      gv[q] = v;
+      gw0[q] = *reinterpret_cast<const f32x4*>(g.gat + (int64_t)max(gi0[q], 0) * g.ldg + n0 + c4);
+      gw1[q] = *reinterpret_cast<const f32x4*>(g.gat + (int64_t)max(gi1[q], 0) * g.ldg + n0 + c4);
     }
   }
 
@@ -355,32 +363,54 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
       for (int q = 0; q < GQ; ++q) {
         const int idx = threadIdx.x + q * 256;
         const int r = idx / GV, c4 = (idx - r * GV) * 4;
-        *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = gv[q];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = (gi0[q] >= 0 ? gw0[q] : zero4) + (gi1[q] >= 0 ? gw1[q] : zero4);
+      }
+    } else if (gvec) {
+      // (128 x 128 tiles: after the K loop, four 16-byte groups per thread at a time, branch-free as above)
+      static_assert((BM * GV) % 1024 == 0 || BM * GV <= 1024, "gather groups");
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      for (int base = 0; base < BM * GV; base += 1024) {
+        int i0[4], i1[4];
+        f32x4 w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 256 + (int)threadIdx.x;
+          const int row = min(m0 + idx / GV, g.M - 1);
+          i0[u] = g.gidx[2 * row];
+          i1[u] = g.gidx[2 * row + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 256 + (int)threadIdx.x;
+          const int r = idx / GV, c4 = (idx - r * GV) * 4;
+          w0[u] = *reinterpret_cast<const f32x4*>(g.gat + (int64_t)max(i0[u], 0) * g.ldg + n0 + c4);
+          w1[u] = *reinterpret_cast<const f32x4*>(g.gat + (int64_t)max(i1[u], 0) * g.ldg + n0 + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 256 + (int)threadIdx.x;
+          const int r = idx / GV, c4 = (idx - r * GV) * 4;
+          if (idx < BM * GV)       // (rows beyond M hold the last row's values: the epilogue never reads them)
+            *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = (i0[u] >= 0 ? w0[u] : zero4) + (i1[u] >= 0 ? w1[u] : zero4);
+        }
       }
     } else {
+      // edge tiles (columns beyond N) and unaligned tables: element by element
       for (int idx = threadIdx.x; idx < BM * GV; idx += 256) {
         const int r = idx / GV, c4 = (idx - r * GV) * 4;
         const int row = m0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < g.M) {
           const int i0 = g.gidx[2 * row], i1 = g.gidx[2 * row + 1];
-          if (gvec) {
-            if (i0 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i0 * g.ldg + n0 + c4);
-            if (i1 >= 0) v += *reinterpret_cast<const f32x4*>(g.gat + (int64_t)i1 * g.ldg + n0 + c4);
-          } else {
-            float e4[4];
+          float e4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int col = n0 + c4 + e;
-              float x = 0.f;
-              if (col < g.N) {
-                if (i0 >= 0) x += g.gat[(int64_t)i0 * g.ldg + col];
-                if (i1 >= 0) x += g.gat[(int64_t)i1 * g.ldg + col];
-              }
-              e4[e] = x;
-            }
-            v = f32x4{e4[0], e4[1], e4[2], e4[3]};
+          for (int e = 0; e < 4; ++e) {
+            const int col = min(n0 + c4 + e, g.N - 1);
+            const float x0 = g.gat[(int64_t)max(i0, 0) * g.ldg + col], x1 = g.gat[(int64_t)max(i1, 0) * g.ldg + col];
+            e4[e] = (i0 >= 0 ? x0 : 0.f) + (i1 >= 0 ? x1 : 0.f);
           }
+          v = f32x4{e4[0], e4[1], e4[2], e4[3]};
         }
         *reinterpret_cast<f32x4*>(&lds[r * BN + c4]) = v;
       }
@@ -403,16 +433,43 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     const bool bnb = g.bn_y != nullptr && col < g.stat_n;
     if (live) {
       const float bv = (g.bias && add_bias) ? g.bias[col] : 0.f;
-      const float bmu = bnb ? g.bn_mean[col] : 0.f, bis = bnb ? g.bn_invstd[col] : 0.f;
+      if (atomic) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        if (row < g.M) {
-          float v = g.alpha * av[e] + bv;
-          float* cp = g.C + (int64_t)row * g.ldc + ocol;
-          if (atomic) {
-            atomicAdd(cp, v);
-          } else {
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          if (row < g.M) atomicAdd(g.C + (int64_t)row * g.ldc + ocol, g.alpha * av[e] + bv);
+        }
+      } else {
+        // Everything the epilogue READS per element (old C for beta, the multiplier, a stored keep mask, the
+        // BatchNorm block's y and z) is loaded for all 16 elements FIRST, from row-clamped addresses, under
+        // block-uniform conditions only: inside the per-element `row < M` branch every load was followed by a
+        // drained load queue - 16 to 48 dependent L2 round trips per MFMA tile.
+        const float bmu = bnb ? g.bn_mean[col] : 0.f, bis = bnb ? g.bn_invstd[col] : 0.f;
+        const bool ld_c = g.beta != 0.f, ld_aux = g.epi == EPI_MUL, ld_keep = g.epi == EPI_LEAKY_DROPOUT && g.keep != nullptr;
+        const bool ld_bn = g.bn_y != nullptr;       // (block-uniform; lanes beyond stat_n read a clamped column and drop it)
+        const int bcol = min(col, g.stat_n - 1);
+        // (eight elements at a time: all sixteen kept the kernel above 128 registers, three waves per SIMD instead of four)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+        float c_old[8], aux[8], by[8], bz[8];
+        uint8_t kp[8];
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const int e = 8 * h + e8;
+          const int64_t rowc = min(row0 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
+          c_old[e8] = ld_c ? g.C[rowc * g.ldc + ocol] : 0.f;
+          aux[e8] = ld_aux ? g.aux_in[rowc * g.ld_aux_in + col] : 1.f;
+          kp[e8] = ld_keep ? g.keep[rowc * g.ld_keep + col] : (uint8_t)0;
+          by[e8] = ld_bn ? g.bn_y[rowc * g.ld_bn_y + bcol] : 0.f;
+          bz[e8] = ld_bn ? g.bn_z[rowc * g.ld_bn_z + bcol] : 0.f;
+        }
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const int e = 8 * h + e8;
+          const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          if (row < g.M) {
+            float v = g.alpha * av[e] + bv;
+            float* cp = g.C + (int64_t)row * g.ldc + ocol;
             if (gather) v += lds[(row - m0) * BN + (col - n0)];
             if (!g.bn_y) {
               cs0 += v;
@@ -421,7 +478,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
             if (g.epi == EPI_LEAKY_DROPOUT) {
               float keep;
               if (g.keep) {
-                keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+                keep = kp[e8] ? 1.f : 0.f;
               } else {
                 keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
               }
@@ -429,18 +486,19 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
               g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
               v *= slope;
             } else if (g.epi == EPI_MUL) {
-              v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+              v *= aux[e8];
             } else if (g.epi == EPI_RELU) {
               v = fmaxf(v, 0.f);
             }
-            if (g.beta != 0.f) v += g.beta * (*cp);
+            if (g.beta != 0.f) v += g.beta * c_old[e8];
             *cp = v;
             if (bnb) {
-              const float dyh = g.bn_y[(int64_t)row * g.ld_bn_y + col] > 0.f ? v : 0.f;
+              const float dyh = by[e8] > 0.f ? v : 0.f;
               cs0 += dyh;
-              cs1 += dyh * ((g.bn_z[(int64_t)row * g.ld_bn_z + col] - bmu) * bis);
+              cs1 += dyh * ((bz[e8] - bmu) * bis);
             }
           }
+        }
         }
       }
     }
@@ -579,25 +637,38 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
 #pragma unroll
   for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&red[w * 1024 + r * 32 + c4]);
   float out[4] = {v.x, v.y, v.z, v.w};
+  // what the epilogue reads, for all four columns first (column-clamped addresses, block-uniform conditions: see
+  // tile_out above)
+  float bias4[4], aux4[4], c_old[4];
+  uint8_t kp[4];
+  const bool ld_keep = g.epi == EPI_LEAKY_DROPOUT && g.keep != nullptr;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int colc = min(n0 + c4 + q, g.N - 1);
+    bias4[q] = g.bias ? g.bias[colc] : 0.f;
+    aux4[q] = g.epi == EPI_MUL ? g.aux_in[(int64_t)row * g.ld_aux_in + colc] : 1.f;
+    c_old[q] = g.beta != 0.f ? g.C[(int64_t)row * g.ldc + colc] : 0.f;
+    kp[q] = ld_keep ? g.keep[(int64_t)row * g.ld_keep + colc] : (uint8_t)0;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int col = n0 + c4 + q;
     if (col >= g.N) continue;
-    float x = g.alpha * out[q] + (g.bias ? g.bias[col] : 0.f);
+    float x = g.alpha * out[q] + bias4[q];
     float* cp = g.C + (int64_t)row * g.ldc + col;
     if (g.epi == EPI_LEAKY_DROPOUT) {
       float keep;
-      if (g.keep) keep = g.keep[(int64_t)row * g.ld_keep + col] ? 1.f : 0.f;
+      if (g.keep) keep = kp[q] ? 1.f : 0.f;
       else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
       const float slope = (x > 0.f ? 1.f : g.leak) * keep * 2.f;
       g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
       x *= slope;
     } else if (g.epi == EPI_MUL) {
-      x *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
+      x *= aux4[q];
     } else if (g.epi == EPI_RELU) {
       x = fmaxf(x, 0.f);
     }
-    if (g.beta != 0.f) x += g.beta * (*cp);
+    if (g.beta != 0.f) x += g.beta * c_old[q];
     *cp = x;
   }
 }
