@@ -141,6 +141,8 @@ extern "C" int dpc_cooccurrence(const uint64_t* bitmaps, int64_t W, int C, int32
 // ---------------------------------------------------------------------------------------------
 // sample_condvec_pair: one wave per sample.
 // ---------------------------------------------------------------------------------------------
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 struct CondvecArgs {
   const int32_t* cnt; const int32_t* cond_st; const int32_t* dims; int nd, C; int64_t N;
   const int32_t* pairs_inj; const double* r_inj; const uint64_t* rng; uint32_t site; int64_t B;
@@ -148,55 +150,70 @@ struct CondvecArgs {
   int32_t* mask; int64_t ldm; int64_t* pair_id; int64_t* val_idx; int32_t* sel; int64_t* gcount;
 };
 
-__global__ __launch_bounds__(256) void condvec_pair_kernel(CondvecArgs a) {
-  const int lane = threadIdx.x & 63;
-  int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= a.B) return;
-  int ca = 0, cb = 0, lo = 0, hi = 0;
+// The walk over the pair's joint values is sequential by definition (an fp64 running sum in cumsum's order), but
+// its LOADS are not: the wave fetches 64 entries of the d1 x d2 count block at a time, every lane converts its own
+// entry, and the running sum then takes the positive entries lane by lane out of registers (ballot + readlane) -
+// one L2 round trip per 64 entries instead of one per entry (lane 0 used to walk alone, load by load).
+__device__ __forceinline__ double condvec_readlane_f64(double v, int l) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__device__ __forceinline__ void condvec_pair_wave(const CondvecArgs& a, const int64_t b, const int lane) {
+  int i, j;
+  double r;
+  if (a.pairs_inj) {
+    i = a.pairs_inj[2 * b];
+    j = a.pairs_inj[2 * b + 1];
+  } else {
+    // ordered draw of two distinct columns (np.random.choice(nd, 2, replace=False) in distribution)
+    float u1 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b));
+    float u2 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 1));
+    i = min(a.nd - 1, (int)(u1 * a.nd));
+    j = min(a.nd - 2, (int)(u2 * (a.nd - 1)));
+    if (j >= i) ++j;
+  }
+  if (a.r_inj) r = a.r_inj[b];
+  else r = dpc_u64_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 2), dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 3));
+  const int lo = min(i, j), hi = max(i, j);
+  const int ka = a.dims[lo], kb = a.dims[hi], sa = a.cond_st[lo], sb = a.cond_st[hi];
+  // the pair's joint values in ascending packed-code order = (va desc, vb desc): entry p is
+  // (va, vb) = (ka-1 - p / kb, kb-1 - p % kb); fp64 running sum of count/N in that order, exactly as cumsum over
+  // counts/sum(counts) does
+  double cum = 0.0;
+  const double dn = (double)a.N;
+  const int total = ka * kb;
+  int found = 0, idx = 0, have_first = 0, fp = 0, fcnt = 0, sp = 0, sidx = 0, scnt = 0;
+  for (int base = 0; base < total && !found; base += 64) {
+    const int p = base + lane;
+    int c = 0;
+    if (p < total) {
+      const int qa = p / kb;
+      c = a.cnt[(int64_t)(sa + ka - 1 - qa) * a.C + sb + (kb - 1 - (p - qa * kb))];
+    }
+    const double t = (double)c / dn;
+    uint64_t live = __ballot(c > 0);
+    while (live) {
+      const int l = __builtin_ctzll(live);
+      live &= live - 1;
+      const int cl = __builtin_amdgcn_readlane(c, l);
+      if (!have_first) { have_first = 1; fp = base + l; fcnt = cl; }
+      cum += condvec_readlane_f64(t, l);
+      if (cum > r) { found = 1; sp = base + l; sidx = idx; scnt = cl; break; }
+      ++idx;
+    }
+  }
+  if (!found) { sp = fp; sidx = 0; scnt = fcnt; }   // argmax of an all-False row is 0
+  const int qa = sp / kb;
+  const int ca = sa + ka - 1 - qa, cb = sb + kb - 1 - (sp - qa * kb);
   if (lane == 0) {
-    int i, j;
-    double r;
-    if (a.pairs_inj) {
-      i = a.pairs_inj[2 * b];
-      j = a.pairs_inj[2 * b + 1];
-    } else {
-      // ordered draw of two distinct columns (np.random.choice(nd, 2, replace=False) in distribution)
-      float u1 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b));
-      float u2 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 1));
-      i = min(a.nd - 1, (int)(u1 * a.nd));
-      j = min(a.nd - 2, (int)(u2 * (a.nd - 1)));
-      if (j >= i) ++j;
-    }
-    if (a.r_inj) r = a.r_inj[b];
-    else r = dpc_u64_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 2), dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 3));
-    lo = min(i, j);
-    hi = max(i, j);
-    const int ka = a.dims[lo], kb = a.dims[hi], sa = a.cond_st[lo], sb = a.cond_st[hi];
-    // walk the pair's joint values in ascending packed-code order = (va desc, vb desc); fp64
-    // running sum of count/N in that order, exactly as cumsum over counts/sum(counts) does
-    double cum = 0.0;
-    const double dn = (double)a.N;
-    int found = 0, idx = 0, fva = 0, fvb = 0, fcnt = 0, have_first = 0, sva = 0, svb = 0, sidx = 0, scnt = 0;
-    for (int va = ka - 1; va >= 0 && !found; --va) {
-      const int32_t* rowp = a.cnt + (int64_t)(sa + va) * a.C + sb;
-      for (int vb = kb - 1; vb >= 0; --vb) {
-        int c = rowp[vb];
-        if (c <= 0) continue;
-        if (!have_first) { have_first = 1; fva = va; fvb = vb; fcnt = c; }
-        cum += (double)c / dn;
-        if (cum > r) { found = 1; sva = va; svb = vb; sidx = idx; scnt = c; break; }
-        ++idx;
-      }
-    }
-    if (!found) { sva = fva; svb = fvb; sidx = 0; scnt = fcnt; }   // argmax of an all-False row is 0
-    ca = sa + sva;
-    cb = sb + svb;
     a.pair_id[b] = (int64_t)lo * a.nd - (int64_t)lo * (lo + 1) / 2 + (hi - lo - 1);
     a.val_idx[b] = sidx;
     if (a.sel) { a.sel[2 * b] = ca; a.sel[2 * b + 1] = cb; }
     if (a.gcount) a.gcount[b] = scnt;
   }
-  ca = __shfl(ca, 0, 64); cb = __shfl(cb, 0, 64); lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
   for (int c = lane; c < a.C; c += 64) {
     float v = (c == ca || c == cb) ? 1.f : 0.f;
     if (a.cond0) a.cond0[b * a.ld0 + c] = v;
@@ -205,6 +222,12 @@ __global__ __launch_bounds__(256) void condvec_pair_kernel(CondvecArgs a) {
   }
   if (a.mask)
     for (int d = lane; d < a.nd; d += 64) a.mask[b * a.ldm + d] = (d == lo || d == hi) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void condvec_pair_kernel(CondvecArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  condvec_pair_wave(a, b, threadIdx.x & 63);
 }
 
 extern "C" int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const int32_t* dims, int nd, int C,
@@ -222,6 +245,71 @@ extern "C" int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_s
   a.cond2 = cond2; a.ld2 = ld2; a.mask = mask; a.ldm = ldm; a.pair_id = pair_id; a.val_idx = val_idx; a.sel = sel;
   a.gcount = gcount;
   hipLaunchKernelGGL(condvec_pair_kernel, dim3((unsigned)dpc_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The inputs of one network update in ONE launch: the cond vectors (condvec_pair_wave above), the latent batch
+// z ~ N(0,1) (the same draws as dpc_fill kind 1: normals 4q..4q+3 of `site_z` are one Philox block) and the zero
+// fill of the update's accumulator pool.  Three independent jobs that used to be three kernel nodes in a row at
+// the top of the step's critical path; here they are block ranges of one grid, the longest job (the cond
+// vectors) first.
+// ---------------------------------------------------------------------------------------------
+struct InputsArgs {
+  CondvecArgs cv;
+  float* z; int64_t ldz, zrows, zcols; uint32_t site_z;
+  f32x4s* zero; int64_t zero_n16;
+  int nb_cv, nb_z;
+};
+
+__global__ __launch_bounds__(256) void step_inputs_kernel(InputsArgs a) {
+  const int bid = blockIdx.x;
+  if (bid < a.nb_cv) {
+    const int64_t b = (int64_t)bid * 4 + (threadIdx.x >> 6);
+    if (b < a.cv.B) condvec_pair_wave(a.cv, b, threadIdx.x & 63);
+  } else if (bid < a.nb_cv + a.nb_z) {
+    const int64_t n = a.zrows * a.zcols, ngrp = (n + 3) / 4;
+    for (int64_t q = (int64_t)(bid - a.nb_cv) * 256 + threadIdx.x; q < ngrp; q += (int64_t)a.nb_z * 256) {
+      float z[4];
+      dpc_normal4(a.cv.rng, a.site_z, (uint64_t)q, z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i < n) {
+          const int64_t r = i / a.zcols, c = i - r * a.zcols;
+          a.z[r * a.ldz + c] = 0.f + 1.f * z[j];
+        }
+      }
+    }
+  } else {
+    const int64_t nb = (int64_t)gridDim.x - a.nb_cv - a.nb_z;
+    const f32x4s zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)(bid - a.nb_cv - a.nb_z) * 256 + threadIdx.x; i < a.zero_n16; i += nb * 256) a.zero[i] = zero4;
+  }
+}
+
+extern "C" int dpc_step_inputs(const int32_t* cnt, const int32_t* cond_st, const int32_t* dims, int nd, int C, int64_t N,
+                               const uint64_t* rng, uint32_t site, int64_t B, float* cond0, int64_t ld0, float* cond1,
+                               int64_t ld1, float* cond2, int64_t ld2, int32_t* mask, int64_t ldm, int64_t* pair_id,
+                               int64_t* val_idx, int32_t* sel, int64_t* gcount, float* z, int64_t ldz, int64_t zrows,
+                               int64_t zcols, uint32_t site_z, void* zero, int64_t zero_bytes, void* stream) {
+  DPC_CHECK_ARG(cnt && cond_st && dims && pair_id && val_idx && rng, "step_inputs: null pointer");
+  DPC_CHECK_ARG(nd >= 2 && C >= 2 && N > 0 && B > 0, "step_inputs: needs >= 2 discrete columns and a batch");
+  DPC_CHECK_ARG(!z || (zrows > 0 && zcols > 0 && ldz >= zcols), "step_inputs: bad latent shape");
+  DPC_CHECK_ARG(zero_bytes >= 0 && zero_bytes % 16 == 0 && (zero || zero_bytes == 0) && (((uintptr_t)zero & 15) == 0),
+                "step_inputs: the zero-filled range must be 16-byte aligned and a multiple of 16 bytes");
+  InputsArgs a;
+  a.cv.cnt = cnt; a.cv.cond_st = cond_st; a.cv.dims = dims; a.cv.nd = nd; a.cv.C = C; a.cv.N = N; a.cv.pairs_inj = nullptr;
+  a.cv.r_inj = nullptr; a.cv.rng = rng; a.cv.site = site; a.cv.B = B; a.cv.cond0 = cond0; a.cv.ld0 = ld0; a.cv.cond1 = cond1;
+  a.cv.ld1 = ld1; a.cv.cond2 = cond2; a.cv.ld2 = ld2; a.cv.mask = mask; a.cv.ldm = ldm; a.cv.pair_id = pair_id;
+  a.cv.val_idx = val_idx; a.cv.sel = sel; a.cv.gcount = gcount;
+  a.z = z; a.ldz = ldz; a.zrows = z ? zrows : 0; a.zcols = z ? zcols : 1; a.site_z = site_z;
+  a.zero = (f32x4s*)zero; a.zero_n16 = zero_bytes / 16;
+  a.nb_cv = (int)dpc_cdiv(B, 4);
+  a.nb_z = z ? dpc_grid((zrows * zcols + 3) / 4, 256) : 0;
+  const int nb_zero = a.zero_n16 ? dpc_grid(dpc_cdiv(a.zero_n16, 4), 256) : 0;       // ~4 x 16 bytes per thread
+  hipLaunchKernelGGL(step_inputs_kernel, dim3((unsigned)(a.nb_cv + a.nb_z + nb_zero)), dim3(256), 0, (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

@@ -494,12 +494,28 @@ class StepEngine(object):
         z0 = self.start[0]
         return c.Hg[:, z0:z0 + self.E], c.Hg[:, z0 + self.E:]
 
-    def _draw_inputs(self, inj, need_real, c):
-        """z, cond vector (+ mask) and, for the discriminator update, the real rows."""
+    def _draw_inputs(self, inj, need_real, c, zero=None):
+        """z, cond vector (+ mask) and, for the discriminator update, the real rows.  ``zero``: the accumulator
+        pool of the update these inputs belong to, cleared here (the discriminator update's own pool when
+        ``need_real``)."""
         zv, cv = self._zc(c)
         B, Dd, C = self.B, self.Dd, self.C
         if need_real:
-            self._disc_gx.zero_()      # the discriminator update's accumulators (gradients, Gram products, BatchNorm sums)
+            zero = self._disc_gx       # the discriminator update's accumulators (gradients, Gram products, BatchNorm sums)
+        if self.has_cond and not any(k in inj for k in ('z', 'cond', 'pairs', 'r')):
+            # pool fill, latent draw and cond vectors are independent of each other: ONE launch (three nodes in a
+            # row at the top of the step's critical path otherwise) with the same draws as the separate calls below
+            s = self.sampler
+            fake_c = None if self.sparse_d else c.X[:, Dd:]
+            ops.step_inputs(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv] + ([] if fake_c is None else [fake_c]), c.mask,
+                            c.pair_id, c.val_idx, c.sel, c.gcount, self.rng, ops.SITE_CONDVEC + self._so, z=zv,
+                            site_z=ops.SITE_Z + self._so, zero=zero)
+            self._join()
+            if need_real:
+                self._draw_real(inj, need_real, c)
+            return
+        if zero is not None:
+            zero.zero_()
         # the latent draw stays on the main stream, in front of the cond-vector sampling: forked beside it,
         # the fork / join pair cost more than the 5 us kernel it hid (0.958 -> 0.950 ms per step)
         if 'z' in inj:
@@ -533,8 +549,12 @@ class StepEngine(object):
                                     c.val_idx, c.sel, c.gcount, pairs_inj=inj.get('pairs'),
                                     r_inj=inj.get('r'), rng=self.rng, site=ops.SITE_CONDVEC + self._so)
         self._join()
-        if not need_real:
-            return
+        if need_real:
+            self._draw_real(inj, need_real, c)
+
+    def _draw_real(self, inj, need_real, c):
+        """Real rows that match the cond vectors of ``c`` (data_sampler.py:382-396) on a side branch."""
+        B, Dd, C = self.B, self.Dd, self.C
         real = self.Xd[B:2 * B]
         with self._fork(0):      # beside the generator forward; joined before the interpolation
             if 'real' in inj:
@@ -560,6 +580,7 @@ class StepEngine(object):
                 # (row, cond id) pairs of the fake and real blocks sorted by id: the cond columns of the first
                 # layer's weight gradient are row sums in that order (_d_back)
                 ops.hot_sort(c.sel, self.C, self.order_d, self.sid_d, self.n_items_d, sel_b=self.sel_real, pac=self.pac)
+                self._probe('real_rows_branch')
             if self.gp_gram:
                 # W1 W1^T of the Gram-form penalty (see _d_back): issued here, beside the generator forward's
                 # chain of small kernels, rather than beside the discriminator's first-layer product
@@ -595,9 +616,16 @@ class StepEngine(object):
         dense input columns; & 2: the cond columns' row sums).  Bias gradients: _gen_bias_grads."""
         gw = self.gen.G('seq.%d.fc.weight' % l if l < self.L else 'seq.%d.weight' % self.L)
         if self.sparse_cond and not self.deterministic:
+            # The output layer's branch starts beside the input-gradient product that the whole backward chain waits
+            # for: its small latency-bound kernel (the row sums) goes first, so the big product meets that chain
+            # ~15 us later (0.802 -> 0.793 ms per step; a delay probe there used to make the step FASTER).  For the
+            # other layers the product first is better (0.782 against 0.787).
+            first = l == self.L
+            if what & 2 and first:
+                ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
             if what & 1:
                 self._mm(dy, c.Hg[:, self.start[l]:self.Wtot - self.C], gw[:, :gw.shape[1] - self.C], trans_a=True, beta=1.0)
-            if what & 2:
+            if what & 2 and not first:
                 ops.hot_rows_sum(dy, c.order, c.sid, c.n_items, self.dWcT[l])
         elif what & 1:
             self._mm(dy, c.Hg[:, self.start[l]:], gw, trans_a=True, beta=1.0)
@@ -878,6 +906,16 @@ class StepEngine(object):
     def _fork(self, k):
         return StepEngine._Fork(self, k)
 
+    def _probe(self, label):
+        """Critical-path probe (tuning aid, off unless DPCGAN_DELAY=<label>:<cycles> is set): a spin node of that many
+        timer cycles (40000 ~ 20 us) at the labelled point of the step, on whatever stream is current.  A step
+        that grows by the delay has that point on its critical path; one that does not has slack there; one
+        that gets FASTER has a branch starting too early beside a product the chain waits for
+        (tools/critical_probe.sh)."""
+        spec = os.environ.get('DPCGAN_DELAY', '')
+        if spec and spec.split(':')[0] == label:
+            torch.cuda._sleep(int(spec.split(':')[1]))
+
     def _join(self):
         if self._inline:         # issuing the early branch: it forks nothing, and the open forks belong to the main stream
             return
@@ -921,8 +959,10 @@ class StepEngine(object):
         from call sites offset by 64*sub and leaves the single end-of-step advance to the caller."""
         inj = inj or {}
         self._so = 0 if sub is None else 64 * sub
+        self._probe('d_inputs')
         self._draw_inputs(inj, need_real=True, c=self.cd)
         self._gen_forward(self.cd)
+        self._probe('g_forward_done')
         self._activate(inj, self.cd, raw=True)
         self._d_back(inj, update, sub)
 
@@ -955,6 +995,7 @@ class StepEngine(object):
                             rng=self.rng, site=ops.SITE_ALPHA + self._so)
             self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
         self._loss_dirty[0] = True
+        self._probe('d_forward_done')
         if self._early_hook is not None:      # see train_step
             self._early_hook()
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
@@ -997,11 +1038,7 @@ class StepEngine(object):
         # (beta = 1: split-K needs no memset node); the first layer's product (K0 wide) runs on the main stream,
         # everything else beside it: the other layers' products, and ONE launch pair for all bias gradients and
         # the head layer's weight gradient (weighted column sums).
-        with self._fork(0):
-            prev = self.H[0]
-            for i in range(1, M):
-                self._mm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0, kscale=kscale)
-                prev = self.H[i]
+        self._probe('d_weight_grads')
         with self._fork(1) as part:
             probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
             probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
@@ -1012,6 +1049,13 @@ class StepEngine(object):
                 # cond columns of dW1: sums of the (clip-scaled) delta rows by hot id, transposed into place below
                 ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
                                  rowscale=kscale[0:2 * n] if kscale is not None else None)
+            # the other layers' products behind the small kernels of this branch: branch 0 carries the penalty's two
+            # products, the main stream the K0-wide one - three lanes of about equal length (0.795 -> 0.786 ms per
+            # step against all products on branch 0)
+            prev = self.H[0]
+            for i in range(1, M):
+                self._mm(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0, kscale=kscale)
+                prev = self.H[i]
         if gram:
             # penalty part (u^T diag(f c) u) W1 beside the fake and real rows' product: both ADD into the zeroed
             # gradient (the penalty part with atomics too - the two run at the same time)
@@ -1037,6 +1081,7 @@ class StepEngine(object):
             C, Dd, gw = self.C, self.Dd, d.G('seq.0.weight')
             ops.transpose_slices([(self.dW1cT[s * C:(s + 1) * C], gw[:, s * self.row + Dd:(s + 1) * self.row])
                                   for s in range(self.pac)], accumulate=True)
+        self._probe('d_grads_done')
         if update:
             self._disc_update(inj)
         if sub is None:
@@ -1080,11 +1125,18 @@ class StepEngine(object):
         gradient buffer, z / cond inputs, generator forward, output activation."""
         self._so = 0 if sub is None else 64 * sub
         c = self.cg
-        self._gen_gx.zero_()   # one fill for all weight gradients: their split-K products then accumulate (beta = 1)
-        self._draw_inputs(inj, need_real=False, c=c)
+        # (the pool fill - one for all weight gradients: their split-K products then accumulate with beta = 1 - rides
+        # in the launch that draws the inputs)
+        self._draw_inputs(inj, need_real=False, c=c, zero=self._gen_gx)
+        self._sort_pending = False
         if self.sparse_cond:
-            with self._fork(1):      # beside the forward; the backward's weight gradients read it
-                ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
+            if self._inline:
+                # on the early lane a fork is not a branch: the sort would sit in front of the lane's first product,
+                # and the lane is as long as the discriminator update it runs beside - _g_back issues it instead
+                self._sort_pending = True
+            else:
+                with self._fork(1):      # beside the forward; the backward's weight gradients read it
+                    ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._gen_forward(c, running=running)
         self._activate_loss(inj, c)
 
@@ -1106,8 +1158,13 @@ class StepEngine(object):
         self._k = 0
         self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
+        if getattr(self, '_sort_pending', False):
+            self._sort_pending = False
+            with self._fork(1):          # joined below, in front of the first weight-gradient branch
+                ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3, sel=c.sel if self.sparse_d else None)
         self._loss_dirty[1] = True
+        self._probe('g_d_forward_done')
         self._disc_chain_down(n, self.rowscale_g)
         # d loss / d D-input (sparse_d: over the data columns only - nothing reads the gradient of the cond columns)
         if self.sparse_d:
@@ -1137,7 +1194,9 @@ class StepEngine(object):
         # the output layer's weight gradient is forked AFTER the input-gradient product: beside it, the two
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
         # would take twice as long; from here on it runs beside that chain's small kernels
+        self._probe('g_dhg_done')
         with self._fork(0):
+            self._probe('g_out_dweight_branch')
             self._gen_dweight(c, L, self.dfake)
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
@@ -1170,6 +1229,7 @@ class StepEngine(object):
                     self._gen_dweight(c, l, self.dZ[l])
         self._gen_bias_grads(self.part)
         self._join()
+        self._probe('g_grads_done')
         if self.sparse_cond and not self.deterministic:
             # the scattered cond-column gradients into their places in the flat gradient buffer
             ops.transpose_slices([(self.dWcT[l], self.gen.G('seq.%d.fc.weight' % l if l < L else 'seq.%d.weight' % L)[:, -self.C:])
@@ -1204,14 +1264,12 @@ class StepEngine(object):
                 self._inline = True
                 try:
                     with torch.cuda.stream(self.early):
-                        self._gen_gx.zero_()
-                        self._draw_inputs({}, need_real=False, c=self.cg)
+                        self._draw_inputs({}, need_real=False, c=self.cg, zero=self._gen_gx)
                 finally:
                     self._inline = False
                 self._pair_sort = self.sparse_cond
             else:
-                self._gen_gx.zero_()
-                self._draw_inputs({}, need_real=False, c=self.cg)
+                self._draw_inputs({}, need_real=False, c=self.cg, zero=self._gen_gx)
                 self._pair_sort = False
                 if self.sparse_cond:
                     with self._fork(1):      # joined by the first collective; the generator backward reads it
@@ -1240,7 +1298,9 @@ class StepEngine(object):
                     self._inline = True
                     try:
                         with torch.cuda.stream(self.early):
+                            self._probe('early_lane_start')
                             self._g_front({}, d_steps, running=False)
+                            self._probe('early_lane_end')
                     finally:
                         self._inline = False
                     self._so = so

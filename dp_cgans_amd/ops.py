@@ -348,6 +348,24 @@ def condvec_pair_sample(cnt, cond_st, dims, N, B, cond_dsts, mask, pair_id, val_
                _p(gcount), _stream())
 
 
+def step_inputs(cnt, cond_st, dims, N, B, cond_dsts, mask, pair_id, val_idx, sel, gcount, rng, site, z=None,
+                site_z=SITE_Z, zero=None):
+    """condvec_pair_sample (Philox-driven) + the latent normal fill of ``z`` + the zero fill of the byte buffer
+    ``zero`` in one launch (dpc_step_inputs)."""
+    nd, C = dims.shape[0], cnt.shape[0]
+    d = list(cond_dsts) + [None] * (3 - len(cond_dsts))
+    args = []
+    for t in d:
+        args += [_p(t), _ld(t) if t is not None else 0]
+    _chk(z, torch.float32, 'z')
+    if zero is not None and (zero.dtype != torch.uint8 or not zero.is_contiguous() or zero.numel() % 16 != 0):
+        raise ValueError('step_inputs: zero must be a contiguous uint8 buffer, a multiple of 16 bytes')
+    lib().call('dpc_step_inputs', _p(cnt), _p(cond_st), _p(dims), nd, C, N, _p(rng), site, B, *args, _p(mask),
+               _ld(mask) if mask is not None else 0, _p(pair_id), _p(val_idx), _p(sel), _p(gcount), _p(z),
+               _ld(z) if z is not None else 0, z.shape[0] if z is not None else 0, z.shape[1] if z is not None else 0,
+               site_z, _p(zero), zero.numel() if zero is not None else 0, _stream())
+
+
 def row_select(bitmaps, sel, gcount, row_id, perm=None, k_inj=None, rng=None, site=SITE_ROWPICK, cntblk=None):
     _chk(perm, torch.int64, 'perm')
     _chk(k_inj, torch.int64, 'k_inj')

@@ -178,6 +178,16 @@ int dpc_condvec_pair_sample(const int32_t* cnt, const int32_t* cond_st, const in
                             float* cond1, int64_t ld1, float* cond2, int64_t ld2, int32_t* mask,
                             int64_t ldm, int64_t* pair_id, int64_t* val_idx, int32_t* sel,
                             int64_t* gcount, void* stream);
+/* The inputs of one network update in ONE launch (three kernel nodes less at the top of the step): the cond
+ * vectors exactly as dpc_condvec_pair_sample draws them from `rng` / `site` (data_sampler.py:245-343), the latent
+ * batch z [zrows][zcols] ~ N(0,1) (fakez = torch.normal(mean, std), dp_cgan.py:598,681; the same draws as dpc_fill
+ * kind 1 at site_z; z nullable) and the zero fill of zero_bytes bytes at `zero` (the update's accumulator pool;
+ * 16-byte aligned, a multiple of 16; nullable with 0 bytes). */
+int dpc_step_inputs(const int32_t* cnt, const int32_t* cond_st, const int32_t* dims, int nd, int C, int64_t N,
+                    const uint64_t* rng, uint32_t site, int64_t B, float* cond0, int64_t ld0, float* cond1,
+                    int64_t ld1, float* cond2, int64_t ld2, int32_t* mask, int64_t ldm, int64_t* pair_id,
+                    int64_t* val_idx, int32_t* sel, int64_t* gcount, float* z, int64_t ldz, int64_t zrows,
+                    int64_t zcols, uint32_t site_z, void* zero, int64_t zero_bytes, void* stream);
 /* sample_data_pair (data_sampler.py:382-396): row_id[b] = k-th smallest row id whose two
  * categories are sel[perm ? perm[b] : b]; k = k_inj[b] or floor(u * gcount).  -1 for an empty group. */
 int dpc_row_select(const uint64_t* bitmaps, int64_t W, const int32_t* sel, const int64_t* gcount,

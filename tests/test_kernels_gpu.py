@@ -604,6 +604,41 @@ def test_sampler_philox_draws_are_valid_and_distributed(ops):
     assert (onehot[row_id, s[:, 0]] == 1).all() and (onehot[row_id, s[:, 1]] == 1).all()
 
 
+def test_step_inputs_equals_the_separate_launches(ops):
+    """dpc_step_inputs (cond vectors + latent draw + pool fill in one launch) against dpc_condvec_pair_sample,
+    dpc_fill and a memset with the same RNG state: bit-identical outputs, nothing written outside its ranges."""
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    table, bitmaps, cnt, cond_st, dims, cat_col = sampler_device_tables(ops, enc, span)
+    C, nd = cnt.shape[0], dims.shape[0]
+    for B, E in ((8192, 128), (37, 5)):
+        rng = ops.new_rng(1234, dev())
+        outs = []
+        for fused in (False, True):
+            cond = torch.full((B, C), -1.0, device=dev())
+            hg = torch.full((B, E + C + 3), -1.0, device=dev())            # z | cond inside a wider row, as in GenContext.Hg
+            mask = torch.full((B, nd), -1, dtype=torch.int32, device=dev())
+            pid = torch.full((B,), -1, dtype=torch.int64, device=dev())
+            vid = torch.full((B,), -1, dtype=torch.int64, device=dev())
+            sel = torch.full((B, 2), -1, dtype=torch.int32, device=dev())
+            gcount = torch.full((B,), -1, dtype=torch.int64, device=dev())
+            pool = torch.full((4096 + 256,), 7, dtype=torch.uint8, device=dev())
+            zv, cv = hg[:, :E], hg[:, E:E + C]
+            if fused:
+                ops.step_inputs(cnt, cond_st, dims, enc.shape[0], B, [cond, cv], mask, pid, vid, sel, gcount, rng,
+                                ops.SITE_CONDVEC + 64, z=zv, site_z=ops.SITE_Z + 64, zero=pool[:4096])
+            else:
+                pool[:4096].zero_()
+                ops.fill(zv, ops.FILL_NORMAL, rng, ops.SITE_Z + 64, 0.0, 1.0)
+                ops.condvec_pair_sample(cnt, cond_st, dims, enc.shape[0], B, [cond, cv], mask, pid, vid, sel, gcount,
+                                        rng=rng, site=ops.SITE_CONDVEC + 64)
+            outs.append([t.clone() for t in (cond, hg, mask, pid, vid, sel, gcount, pool)])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert (outs[1][7][4096:] == 7).all() and (outs[1][1][:, E + C:] == -1).all()
+        assert (outs[1][0].sum(1) == 2).all()
+
+
 def test_encode_bit_exact_against_reference(ops):
     from oracle import encode as oenc
     z = load('adult_encode.npz')
