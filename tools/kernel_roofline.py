@@ -63,6 +63,10 @@ def algorithmic_bytes_per_step(c):
         'gp_gram_rows_kernel': 16.0 * n * d[0],
         'disc_first_act_kernel<true>': 4.0 * d[0] * ((2 * n + 2 * 3 * n + 2 * n) + (n + 2 * n)),
         'condvec_pair_kernel': 2 * (4.0 * B * 2 + 4.0 * B * c['n_discrete']),
+        # both updates' inputs: cond vector twice (own copy + the generator-input columns), mask, latent batch, and
+        # the zero fill of the two accumulator pools (flat gradients, transposed cond-column gradients, Gram products)
+        'step_inputs_kernel': 2 * (8.0 * B * C + 4.0 * B * c['n_discrete'] + 4.0 * B * c['embedding_dim'])
+                              + 4.0 * (c['disc_params'] + c['gen_params'] + 2 * d[0] * d[0] + pac * C * d[0] + C * (sum(g) + Dd)),
     }
 
 
