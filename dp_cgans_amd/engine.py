@@ -927,11 +927,15 @@ class StepEngine(object):
     def _allreduce(self, t):
         if not self.dist.active:
             return t
-        self._join()             # a collective (and a graph cut) needs every branch back on the main stream
-        self._join_early()
-        if self._ar_hook is not None:      # graph capture in progress: the collective runs between graph segments
+        if self._ar_hook is not None:      # graph capture in progress, the collective runs between graph segments:
+            self._join()                   # a graph cut needs every branch back on the main stream
+            self._join_early()
             self._ar_hook(t)
             return t
+        # In the graph (or eager) the collective is one more node of the main stream: what it reduces was produced on
+        # the main stream (or joined into it by the caller), and the branches that are open - weight-gradient products,
+        # the other lane's activation - keep running beside it.  (Joining them here put every weight-gradient product
+        # of the generator's backward in front of the next BatchNorm all-reduce: 0.916 -> 0.839 ms forced onto one rank.)
         return self.dist.allreduce(t)
 
     def _sync_sums(self, part, R, width):
