@@ -753,9 +753,12 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
   DPC_CHECK_ARG(!d.kscale || !a_kc, "gemm: kscale needs an m-contiguous A (the weight-gradient product)");
   g.kscale = d.kscale;
   g.gat = d.gat; g.ldg = d.ldg; g.gidx = d.gidx;
-  const int64_t lda = a_kc ? d.a_rs : d.a_cs, ldb = b_kc ? d.b_cs : d.b_rs;
-  g.a_vec = (((uintptr_t)d.A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
-  g.b_vec = (((uintptr_t)d.B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  const int64_t ldb = b_kc ? d.b_cs : d.b_rs;
+  // the 16-byte staging loads are typed dword-aligned (f32x4u): any fp32 operand takes them, whatever its row length
+  // (a cond vector of C % 4 != 0 columns would otherwise push every product of the generator onto the element-wise
+  // edge path).  The flags stay in the argument block for the tile kernels' edge logic.
+  g.a_vec = 1;
+  g.b_vec = 1;
   // segment maps (GemmArgs::seg_*)
   g.seg_b = d.seg_b; g.seg_c = d.seg_c; g.seg_len = d.seg_len; g.seg_pad = d.seg_pad; g.seg_stride = d.seg_stride;
   g.colstat = d.colstat;

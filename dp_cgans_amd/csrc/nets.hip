@@ -448,22 +448,49 @@ __device__ __forceinline__ void bn_strip_sums(const double* __restrict__ part, i
   s1 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
 }
 
+// VEC: F % 4 == 0 and 16-byte aligned rows - the row walk then moves four columns per thread (16 threads per row of
+// the strip, 16 rows per pass) with the per-column constants handed over through LDS; same arithmetic per element.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_relu_fwd_fused_kernel(BnFusedArgs a) {
   __shared__ double red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float cst[4][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + c;
   double s0, s1;
   bn_strip_sums(a.part, a.R, a.F, f, c, rl, red, s0, s1);
-  if (f >= a.F) return;
-  float mean, invstd;
-  const bool writer = blockIdx.y == 0 && rl == 0;
-  bn_stats(s0, s1, a.count, a.eps, mean, invstd, writer ? a.run_mean : nullptr, a.run_var, f, a.momentum);
-  if (writer) {
-    a.mean_out[f] = mean;
-    a.invstd_out[f] = invstd;
+  float mean = 0.f, invstd = 0.f, ga = 0.f, be = 0.f;
+  if (f < a.F) {
+    const bool writer = blockIdx.y == 0 && rl == 0;
+    bn_stats(s0, s1, a.count, a.eps, mean, invstd, writer ? a.run_mean : nullptr, a.run_var, f, a.momentum);
+    if (writer) {
+      a.mean_out[f] = mean;
+      a.invstd_out[f] = invstd;
+    }
+    ga = a.gamma[f];
+    be = a.beta[f];
   }
-  const float ga = a.gamma[f], be = a.beta[f];
   const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
+  if (VEC) {
+    if (rl == 0) { cst[0][c] = mean; cst[1][c] = invstd; cst[2][c] = ga; cst[3][c] = be; }
+    __syncthreads();
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;
+    const int f4 = blockIdx.x * 64 + c4;
+    if (f4 >= a.F) return;
+    const float4 m4 = *reinterpret_cast<const float4*>(&cst[0][c4]), i4 = *reinterpret_cast<const float4*>(&cst[1][c4]);
+    const float4 g4 = *reinterpret_cast<const float4*>(&cst[2][c4]), b4 = *reinterpret_cast<const float4*>(&cst[3][c4]);
+#pragma unroll 4
+    for (int64_t r = r0 + rr; r < r1; r += 16) {
+      const float4 z = *reinterpret_cast<const float4*>(a.z + r * a.ldz + f4);
+      float4 y;
+      y.x = fmaxf((z.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+      y.y = fmaxf((z.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+      y.z = fmaxf((z.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+      y.w = fmaxf((z.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+      *reinterpret_cast<float4*>(a.y + r * a.ldy + f4) = y;
+    }
+    return;
+  }
+  if (f >= a.F) return;
 #pragma unroll 8
   for (int64_t r = r0 + rl; r < r1; r += 4) {
     const float v = (a.z[r * a.ldz + f] - mean) * invstd * ga + be;
@@ -489,7 +516,9 @@ extern "C" int dpc_bn_relu_fwd_fused(const float* z, int64_t ldz, float* y, int6
   if (chunks < 1) chunks = 1;
   a.rows_per_block = dpc_cdiv(B, chunks);
   chunks = dpc_cdiv(B, a.rows_per_block);
-  hipLaunchKernelGGL(bn_relu_fwd_fused_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  const bool vec = (F % 4 == 0) && (ldz % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)z | (uintptr_t)y) & 15) == 0);
+  if (vec) hipLaunchKernelGGL(bn_relu_fwd_fused_kernel<true>, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bn_relu_fwd_fused_kernel<false>, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }
@@ -503,21 +532,54 @@ struct BnBwdFusedArgs {
   float out_scale;     // dbeta / dgamma are written times this (1/world: they are global sums already, see the entry point)
 };
 
+template <bool VEC>      // (as the forward: four columns per thread in the row walk)
 __global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(BnBwdFusedArgs a) {
   __shared__ double red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float cst[5][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + c;
   double s0, s1;
   bn_strip_sums(a.part, a.R, a.F, f, c, rl, red, s0, s1);
-  if (f >= a.F) return;
   const float db = (float)s0, dg = (float)s1;
-  if (blockIdx.y == 0 && rl == 0) {
-    a.dbeta[f] = db * a.out_scale;
-    a.dgamma[f] = dg * a.out_scale;
+  float mu = 0.f, is = 0.f, ga = 0.f;
+  if (f < a.F) {
+    if (blockIdx.y == 0 && rl == 0) {
+      a.dbeta[f] = db * a.out_scale;
+      a.dgamma[f] = dg * a.out_scale;
+    }
+    mu = a.mean[f]; is = a.invstd[f]; ga = a.gamma[f];
   }
-  const float mu = a.mean[f], is = a.invstd[f], ga = a.gamma[f];
   const float inv_count = (float)(1.0 / a.count);
   const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
+  if (VEC) {
+    if (rl == 0) { cst[0][c] = mu; cst[1][c] = is; cst[2][c] = ga; cst[3][c] = db; cst[4][c] = dg; }
+    __syncthreads();
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;
+    const int f4 = blockIdx.x * 64 + c4;
+    if (f4 >= a.F) return;
+    float mu4[4], is4[4], ga4[4], db4[4], dg4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mu4[e] = cst[0][c4 + e]; is4[e] = cst[1][c4 + e]; ga4[e] = cst[2][c4 + e]; db4[e] = cst[3][c4 + e]; dg4[e] = cst[4][c4 + e];
+    }
+#pragma unroll 2
+    for (int64_t r = r0 + rr; r < r1; r += 16) {
+      const float4 y = *reinterpret_cast<const float4*>(a.y + r * a.ldy + f4);
+      const float4 dy = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + f4);
+      const float4 z = *reinterpret_cast<const float4*>(a.z + r * a.ldz + f4);
+      const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w}, zv[4] = {z.x, z.y, z.z, z.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dyh = yv[e] > 0.f ? dv[e] : 0.f;
+        const float xh = (zv[e] - mu4[e]) * is4[e];
+        o[e] = ga4[e] * is4[e] * (dyh - db4[e] * inv_count - xh * dg4[e] * inv_count);
+      }
+      *reinterpret_cast<float4*>(a.dz + r * a.lddz + f4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
+  if (f >= a.F) return;
 #pragma unroll 4
   for (int64_t r = r0 + rl; r < r1; r += 4) {
     const float dyh = a.y[r * a.ldy + f] > 0.f ? a.dy[r * a.lddy + f] : 0.f;
@@ -547,7 +609,10 @@ extern "C" int dpc_bn_relu_bwd_fused(const float* dy, int64_t lddy, const float*
   if (chunks < 1) chunks = 1;
   a.rows_per_block = dpc_cdiv(B, chunks);
   chunks = dpc_cdiv(B, a.rows_per_block);
-  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  const bool vec = (F % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (ldz % 4 == 0) && (lddz % 4 == 0) &&
+                   ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz) & 15) == 0);
+  if (vec) hipLaunchKernelGGL(bn_relu_bwd_fused_kernel<true>, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bn_relu_bwd_fused_kernel<false>, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
   DPC_LAUNCH_CHECK();
   return DPC_OK;
 }

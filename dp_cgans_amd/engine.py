@@ -139,7 +139,7 @@ class GenContext(object):
     def __init__(self, eng, X):
         d, B = eng.dev, eng.B
         f32 = dict(device=d, dtype=torch.float32)
-        self.Hg = torch.zeros(B, eng.Wtot, **f32)
+        self.Hg = torch.zeros(B, (eng.Wtot + 3) // 4 * 4, **f32)[:, :eng.Wtot]       # rows padded to 16 bytes, as fake below
         self.Z = [torch.zeros(B, w, **f32) for w in eng.gdim]
         self.bn_mean = [torch.zeros(w, **f32) for w in eng.gdim]
         self.bn_invstd = [torch.zeros(w, **f32) for w in eng.gdim]
@@ -285,7 +285,7 @@ class StepEngine(object):
         # ---- activations / workspaces ----------------------------------------------------------
         B, n = self.B, self.n
         f32 = dict(device=d, dtype=torch.float32)
-        self.dHg = torch.zeros(B, self.Wtot, **f32)
+        self.dHg = torch.zeros(B, (self.Wtot + 3) // 4 * 4, **f32)[:, :self.Wtot]
         self.dZ = [torch.zeros(B, w, **f32) for w in self.gdim]
         ldd = (self.Dd + 3) // 4 * 4          # rows padded to 16 bytes: keeps the GEMM's vector path
         self.dfake = torch.zeros(B, ldd, **f32)[:, :self.Dd]
