@@ -96,16 +96,70 @@ extern "C" int dpc_fill(void* out, int kind, int64_t ld, int64_t rows, int64_t c
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);  p = clamp(p, +-clamp) if clamp > 0
 // Algorithmic HBM traffic: 16 B read + 12 B written per parameter (+4 with an injected noise tensor).
 // ---------------------------------------------------------------------------------------------
+#define DPC_ADAM_MAX_SLICES 16
+#define DPC_ADAM_MAX_MATS 8
+// A parameter matrix [rows][ld] at flat offset `off` whose columns c with (c mod period) >= col0 belong to cond
+// slices: the flat blocks leave those elements to the tile blocks.  ld / period divisions by multiply-shift
+// (x < 2^31: q = (x * m) >> s is exact for m = ceil(2^s / d), s = 31 + ceil(log2 d)).
+struct AdamMat { int64_t off, end; uint32_t ld, ld_m, ld_s, period, per_m, per_s, col0; };
+// One cond slice: columns [col0, col0 + ncol) of the rows of a parameter matrix.  gT (nullable): transposed gradient
+// addend [ncol][ld_gT], g += gT[c][row] (the sorted row sums of dpc_hot_rows_sum), the sum written back to g;
+// pT (nullable): transposed copy of the UPDATED parameters [ncol][ld_pT] (W[:, cond]^T, the row-gather table of the
+// forward).  tile0: first tile block of the slice.
+struct AdamSlice { int64_t off; int rows, ld, col0, ncol; const float* gT; int64_t ld_gT; float* pT; int64_t ld_pT; int tile0; };
+
 struct AdamArgs {
-  float* p; const float* g; float* m; float* v; int64_t n;
+  float* p; float* g; float* m; float* v; int64_t n;
   float lr, b1, b2, eps, wd, clamp, gscale;
   const int32_t* t_dev; int t_host;
   const int64_t* seg_off; const float* seg_add; int nseg;
   float noise_scale; const float* noise_inj; const uint64_t* rng; uint32_t site;
+  int flat_blocks, tile_blocks, nmat, nslice;
+  AdamMat mat[DPC_ADAM_MAX_MATS];
+  AdamSlice sl[DPC_ADAM_MAX_SLICES];
 };
+
+__device__ __forceinline__ uint32_t adam_div(uint32_t x, uint32_t m, uint32_t s) {
+  return (uint32_t)(((uint64_t)x * m) >> s);
+}
+
+// does flat element i belong to a cond slice (tile blocks update it)?
+__device__ __forceinline__ bool adam_in_slice(const AdamArgs& a, int64_t i) {
+  for (int k = 0; k < a.nmat; ++k) {
+    const AdamMat& t = a.mat[k];
+    if (i >= t.off && i < t.end) {
+      const uint32_t x = (uint32_t)(i - t.off);
+      const uint32_t col = x - adam_div(x, t.ld_m, t.ld_s) * t.ld;
+      const uint32_t cc = col - adam_div(col, t.per_m, t.per_s) * t.period;
+      return cc >= t.col0;
+    }
+  }
+  return false;
+}
+
+// (FMA contraction off: the flat blocks and the tile blocks of one launch must give an element the same update to
+// the bit, whichever of them owns it - left to the compiler, v came out one ulp apart between the two call sites)
+// 0: no element of the quad i0 .. i0+3 belongs to a cond slice; 1: all four do; 2: look at each
+__device__ __forceinline__ int adam_quad_class(const AdamArgs& a, int64_t i0) {
+  for (int k = 0; k < a.nmat; ++k) {
+    const AdamMat& t = a.mat[k];
+    if (i0 + 3 >= t.off && i0 < t.end) {
+      if (i0 < t.off || i0 + 3 >= t.end) return 2;
+      const uint32_t x = (uint32_t)(i0 - t.off);
+      const uint32_t col = x - adam_div(x, t.ld_m, t.ld_s) * t.ld;
+      if (col + 3 >= t.ld) return 2;
+      const uint32_t cc = col - adam_div(col, t.per_m, t.per_s) * t.period;
+      if (cc + 3 >= t.period) return 2;
+      if (cc >= t.col0) return 1;
+      return cc + 3 < t.col0 ? 0 : 2;
+    }
+  }
+  return 0;
+}
 
 __device__ __forceinline__ float adam_one(const AdamArgs& a, int64_t i, float g, float p, float& m, float& v,
                                           float z, float step_size, float bc2s) {
+#pragma clang fp contract(off)
   g *= a.gscale;
   if (a.nseg > 0) {
     int s = 0;
@@ -122,24 +176,156 @@ __device__ __forceinline__ float adam_one(const AdamArgs& a, int64_t i, float g,
   return p;
 }
 
+// A 32 x 32 tile of a cond slice: the transposed gradient addend comes in through LDS, the elements take the same
+// update as the flat blocks give (same flat index for the segment lookup and the noise draw), and the updated
+// parameters leave through LDS into the transposed copy.  256 threads, four elements each per phase, every global
+// access coalesced along its own buffer's rows.
+typedef float adam_f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at dword alignment
+
+__device__ __forceinline__ void adam_slice_tile(const AdamArgs& a, int tb, float step_size, float bc2s, float (*t)[33]) {
+  int k = 0;
+  while (k + 1 < a.nslice && tb >= a.sl[k + 1].tile0) ++k;
+  const AdamSlice& sl = a.sl[k];
+  const int tcols = (sl.ncol + 31) >> 5;
+  const int lt = tb - sl.tile0;
+  const int r0 = (lt / tcols) * 32, c0 = (lt % tcols) * 32;
+  const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;       // hi: 0..7
+  const bool noisy = a.noise_scale != 0.f;
+  float gt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (sl.gT) {          // (the addend tile's loads are in flight together with the update's own loads below)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = min(c0 + hi + 8 * q, sl.ncol - 1), r2 = min(r0 + lo, sl.rows - 1);
+      gt[q] = sl.gT[(int64_t)cc * sl.ld_gT + r2];
+    }
+  }
+  // the update: thread (rr = tid / 8, c4 = 4 * (tid % 8)) owns columns c4 .. c4+3 of row rr - one 16-byte access
+  // per buffer when the four lie inside the slice (all but the slice's last partial group), element-wise otherwise
+  const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  const bool rok = r0 + rr < sl.rows;
+  const int nc = rok ? max(0, min(4, sl.ncol - (c0 + c4))) : 0;          // live columns of this thread
+  const int64_t i0 = sl.off + (int64_t)min(r0 + rr, sl.rows - 1) * sl.ld + sl.col0 + c0 + c4;
+  float gg[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+  float zz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (nc == 4) {
+    const adam_f4u g4 = *reinterpret_cast<const adam_f4u*>(a.g + i0), p4 = *reinterpret_cast<const adam_f4u*>(a.p + i0);
+    const adam_f4u m4 = *reinterpret_cast<const adam_f4u*>(a.m + i0), v4 = *reinterpret_cast<const adam_f4u*>(a.v + i0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gg[e] = g4[e]; pp[e] = p4[e]; mm[e] = m4[e]; vv[e] = v4[e]; }
+    if (noisy && a.noise_inj) {
+      const adam_f4u z4 = *reinterpret_cast<const adam_f4u*>(a.noise_inj + i0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zz[e] = z4[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nc) {
+        gg[e] = a.g[i0 + e]; pp[e] = a.p[i0 + e]; mm[e] = a.m[i0 + e]; vv[e] = a.v[i0 + e];
+        if (noisy && a.noise_inj) zz[e] = a.noise_inj[i0 + e];
+      }
+    }
+  }
+  if (noisy && !a.noise_inj && nc > 0) {
+    // the four flat indices i0 .. i0+3 span at most two Philox blocks
+    float za[4], zb[4];
+    dpc_normal4(a.rng, a.site, (uint64_t)(i0 >> 2), za);
+    dpc_normal4(a.rng, a.site, (uint64_t)((i0 + 3) >> 2), zb);
+    const int sh = (int)(i0 & 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = sh + e;              // 0..6: element j of the pair of blocks
+      const float lo4 = (j & 3) == 0 ? za[0] : ((j & 3) == 1 ? za[1] : ((j & 3) == 2 ? za[2] : za[3]));
+      const float hi4 = (j & 3) == 0 ? zb[0] : ((j & 3) == 1 ? zb[1] : ((j & 3) == 2 ? zb[2] : zb[3]));
+      zz[e] = j < 4 ? lo4 : hi4;
+    }
+  }
+  if (sl.gT) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[hi + 8 * q][lo] = gt[q];       // (entries beyond the slice's edge are never read)
+    __syncthreads();
+  }
+  float pn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < nc) {
+      if (sl.gT) gg[e] += t[c4 + e][rr];
+      pn[e] = adam_one(a, i0 + e, gg[e], pp[e], mm[e], vv[e], zz[e], step_size, bc2s);
+    }
+  }
+  if (nc == 4) {
+    if (sl.gT) *reinterpret_cast<adam_f4u*>(a.g + i0) = adam_f4u{gg[0], gg[1], gg[2], gg[3]};
+    *reinterpret_cast<adam_f4u*>(a.p + i0) = adam_f4u{pn[0], pn[1], pn[2], pn[3]};
+    *reinterpret_cast<adam_f4u*>(a.m + i0) = adam_f4u{mm[0], mm[1], mm[2], mm[3]};
+    *reinterpret_cast<adam_f4u*>(a.v + i0) = adam_f4u{vv[0], vv[1], vv[2], vv[3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nc) {
+        if (sl.gT) a.g[i0 + e] = gg[e];
+        a.p[i0 + e] = pn[e]; a.m[i0 + e] = mm[e]; a.v[i0 + e] = vv[e];
+      }
+    }
+  }
+  if (sl.pT) {
+    __syncthreads();                 // the addend tile has been consumed
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[c4 + e][rr] = pn[e];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = hi + 8 * q, r2 = lo;
+      if (c0 + cc < sl.ncol && r0 + r2 < sl.rows) sl.pT[(int64_t)(c0 + cc) * sl.ld_pT + r0 + r2] = t[cc][r2];
+    }
+  }
+}
+
 // VEC: all four buffers (and the injected noise) are 16-byte aligned; each thread owns 4 consecutive
 // parameters = one Philox block of noise.
 template <bool VEC>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __shared__ float bc[2];
+  __shared__ float tile[32][33];
   if (threadIdx.x == 0) {
+    // beta^t for the integer step count by repeated squaring (pow() in fp64 is some hundred dependent instructions
+    // that every block of the launch would sit behind at its first barrier)
     int t = (a.t_dev ? a.t_dev[0] : 0) + a.t_host;
-    bc[0] = (float)(a.lr / (1.0 - pow((double)a.b1, (double)t)));
-    bc[1] = (float)sqrt(1.0 - pow((double)a.b2, (double)t));
+    double p1 = 1.0, p2 = 1.0, x1 = (double)a.b1, x2 = (double)a.b2;
+    for (int e = t; e > 0; e >>= 1) {
+      if (e & 1) { p1 *= x1; p2 *= x2; }
+      x1 *= x1; x2 *= x2;
+    }
+    bc[0] = (float)(a.lr / (1.0 - p1));
+    bc[1] = (float)sqrt(1.0 - p2);
   }
   __syncthreads();
   const float step_size = bc[0], bc2s = bc[1];
+  // the tile blocks come FIRST in the grid: they have the longer life (three barriers, two passes through LDS) and
+  // the flat blocks fill in around them
+  if ((int)blockIdx.x < a.tile_blocks) {
+    adam_slice_tile(a, (int)blockIdx.x, step_size, bc2s, tile);
+    return;
+  }
+  const int fb = (int)blockIdx.x - a.tile_blocks;
   const bool noisy = a.noise_scale != 0.f;
   const int64_t nq = (a.n + 3) >> 2;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = (int64_t)fb * blockDim.x + threadIdx.x; q < nq; q += (int64_t)a.flat_blocks * blockDim.x) {
     const int64_t i0 = q << 2;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (noisy && !a.noise_inj) dpc_normal4(a.rng, a.site, (uint64_t)q, z);
+    // elements of cond slices are the tile blocks' (block-uniform nmat == 0: nothing to test)
+    bool skip[4] = {false, false, false, false};
+    if (a.nmat > 0) {
+      // one pair of divisions classifies a quad that lies inside one row and one period of its matrix (all but the
+      // quads on a boundary): all ours, or all a tile block's
+      int cls = adam_quad_class(a, i0);
+      if (cls == 1) continue;
+      if (cls == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) skip[j] = adam_in_slice(a, i0 + j);
+        if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
+      }
+    }
     if (VEC && i0 + 4 <= a.n) {
       float4 p = *reinterpret_cast<const float4*>(a.p + i0), g = *reinterpret_cast<const float4*>(a.g + i0);
       float4 m = *reinterpret_cast<const float4*>(a.m + i0), v = *reinterpret_cast<const float4*>(a.v + i0);
@@ -151,14 +337,24 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
       p.y = adam_one(a, i0 + 1, g.y, p.y, m.y, v.y, z[1], step_size, bc2s);
       p.z = adam_one(a, i0 + 2, g.z, p.z, m.z, v.z, z[2], step_size, bc2s);
       p.w = adam_one(a, i0 + 3, g.w, p.w, m.w, v.w, z[3], step_size, bc2s);
-      *reinterpret_cast<float4*>(a.p + i0) = p;
-      *reinterpret_cast<float4*>(a.m + i0) = m;
-      *reinterpret_cast<float4*>(a.v + i0) = v;
+      if (a.nmat > 0 && (skip[0] || skip[1] || skip[2] || skip[3])) {
+        // a quad that touches a cond slice: element-wise stores of the elements that are ours (the tile blocks
+        // write the others in this same launch)
+        const float pv[4] = {p.x, p.y, p.z, p.w}, mv[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!skip[j]) { a.p[i0 + j] = pv[j]; a.m[i0 + j] = mv[j]; a.v[i0 + j] = vv[j]; }
+        }
+      } else {
+        *reinterpret_cast<float4*>(a.p + i0) = p;
+        *reinterpret_cast<float4*>(a.m + i0) = m;
+        *reinterpret_cast<float4*>(a.v + i0) = v;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int64_t i = i0 + j;
-        if (i < a.n) {
+        if (i < a.n && !skip[j]) {
           float m = a.m[i], v = a.v[i];
           float zz = (noisy && a.noise_inj) ? a.noise_inj[i] : z[j];
           a.p[i] = adam_one(a, i, a.g[i], a.p[i], m, v, zz, step_size, bc2s);
@@ -169,27 +365,108 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
-extern "C" int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                             float b2, float eps, float wd, float clamp, float gscale, const int32_t* t_dev,
-                             int t_host, const int64_t* seg_off, const float* seg_add, int nseg,
-                             float noise_scale, const float* noise_inj, const uint64_t* rng, uint32_t site,
-                             void* stream) {
+static void adam_magic(uint32_t d, uint32_t& m, uint32_t& s) {
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  s = 31 + l;
+  m = (uint32_t)(((1ull << s) + d - 1) / d);
+}
+
+static int adam_launch(AdamArgs& a, void* stream) {
+  const uintptr_t al = (uintptr_t)a.p | (uintptr_t)a.g | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)a.noise_inj;
+  a.flat_blocks = dpc_grid((a.n + 3) / 4, 256);
+  int tiles = 0;
+  for (int k = 0; k < a.nslice; ++k) {
+    a.sl[k].tile0 = tiles;
+    tiles += (int)(dpc_cdiv(a.sl[k].rows, 32) * dpc_cdiv(a.sl[k].ncol, 32));
+  }
+  a.tile_blocks = tiles;
+  const dim3 grid((unsigned)(a.flat_blocks + tiles));
+  if ((al & 15) == 0) hipLaunchKernelGGL(adam_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(adam_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  DPC_LAUNCH_CHECK();
+  return DPC_OK;
+}
+
+static int adam_fill(AdamArgs& a, float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                     float wd, float clamp, float gscale, const int32_t* t_dev, int t_host, const int64_t* seg_off,
+                     const float* seg_add, int nseg, float noise_scale, const float* noise_inj, const uint64_t* rng,
+                     uint32_t site) {
   DPC_CHECK_ARG(p && g && m && v, "adam: null pointer");
   DPC_CHECK_ARG(n >= 0, "adam: negative size");
   DPC_CHECK_ARG(t_host >= 1, "adam: step count offset must be >= 1");
   DPC_CHECK_ARG(nseg == 0 || (seg_off && seg_add), "adam: segment table missing");
   DPC_CHECK_ARG(noise_scale == 0.f || noise_inj || rng, "adam: noise requested without a source");
-  if (n == 0) return DPC_OK;
-  AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
   a.clamp = clamp; a.gscale = gscale; a.t_dev = t_dev; a.t_host = t_host; a.seg_off = seg_off;
   a.seg_add = seg_add; a.nseg = nseg; a.noise_scale = noise_scale; a.noise_inj = noise_inj; a.rng = rng;
-  a.site = site;
-  const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)noise_inj;
-  if ((al & 15) == 0) hipLaunchKernelGGL(adam_kernel<true>, dim3(dpc_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(adam_kernel<false>, dim3(dpc_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
-  DPC_LAUNCH_CHECK();
+  a.site = site; a.nmat = 0; a.nslice = 0;
   return DPC_OK;
+}
+
+extern "C" int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                             float b2, float eps, float wd, float clamp, float gscale, const int32_t* t_dev,
+                             int t_host, const int64_t* seg_off, const float* seg_add, int nseg,
+                             float noise_scale, const float* noise_inj, const uint64_t* rng, uint32_t site,
+                             void* stream) {
+  AdamArgs a;
+  int rc = adam_fill(a, p, const_cast<float*>(g), m, v, n, lr, b1, b2, eps, wd, clamp, gscale, t_dev, t_host, seg_off, seg_add,
+                     nseg, noise_scale, noise_inj, rng, site);
+  if (rc != DPC_OK) return rc;
+  if (n == 0) return DPC_OK;
+  return adam_launch(a, stream);
+}
+
+// The same step over a parameter buffer that holds matrices with COND SLICES (columns that multiply a two-hot cond
+// vector; the generator's Linears over cat([.., cond]), the discriminator's first Linear over pac sub-rows
+// [data | cond]: dp_cgan.py:66-68,83,606,622-623).  For slice k = columns [s_col0[k], s_col0[k] + s_ncol[k]) of the
+// matrix of s_rows[k] rows of length s_ld[k] at flat offset s_off[k]: the gradient takes the transposed addend
+// s_gT[k] [ncol][s_ld_gT[k]] (nullable; the sum is written back to g) and the updated parameters are also written
+// transposed to s_pT[k] [ncol][s_ld_pT[k]] (nullable) - what two dpc_transpose_slices launches around dpc_adam_step
+// did, in the one launch.  The nmat matrices that own the slices: offset m_off, rows m_rows, row length m_ld; their
+// cond columns are those with (column mod m_period) >= m_col0.  All arrays are HOST arrays.
+extern "C" int dpc_adam_step_slices(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                    float eps, float wd, float clamp, float gscale, const int32_t* t_dev, int t_host,
+                                    const int64_t* seg_off, const float* seg_add, int nseg, float noise_scale,
+                                    const float* noise_inj, const uint64_t* rng, uint32_t site, int nmat,
+                                    const int64_t* m_off, const int* m_rows, const int* m_ld, const int* m_period,
+                                    const int* m_col0, int nslice, const int64_t* s_off, const int* s_rows,
+                                    const int* s_ld, const int* s_col0, const int* s_ncol, const float* const* s_gT,
+                                    const int64_t* s_ld_gT, float* const* s_pT, const int64_t* s_ld_pT, void* stream) {
+  AdamArgs a;
+  int rc = adam_fill(a, p, g, m, v, n, lr, b1, b2, eps, wd, clamp, gscale, t_dev, t_host, seg_off, seg_add, nseg, noise_scale,
+                     noise_inj, rng, site);
+  if (rc != DPC_OK) return rc;
+  DPC_CHECK_ARG(nmat >= 0 && nmat <= DPC_ADAM_MAX_MATS && nslice >= 0 && nslice <= DPC_ADAM_MAX_SLICES, "adam_slices: at most 8 matrices and 16 slices");
+  DPC_CHECK_ARG(nmat == 0 || (m_off && m_rows && m_ld && m_period && m_col0), "adam_slices: matrix table missing");
+  DPC_CHECK_ARG(nslice == 0 || (s_off && s_rows && s_ld && s_col0 && s_ncol && s_gT && s_ld_gT && s_pT && s_ld_pT), "adam_slices: slice table missing");
+  if (n == 0) return DPC_OK;
+  for (int k = 0; k < nmat; ++k) {
+    DPC_CHECK_ARG(m_off[k] >= 0 && m_rows[k] > 0 && m_ld[k] > 0 && m_period[k] > 0 && m_period[k] <= m_ld[k] && m_col0[k] >= 0 &&
+                  m_col0[k] <= m_period[k] && m_off[k] + (int64_t)m_rows[k] * m_ld[k] <= n && (int64_t)m_rows[k] * m_ld[k] < (1ll << 31),
+                  "adam_slices: bad matrix");
+    AdamMat& t = a.mat[k];
+    t.off = m_off[k]; t.end = m_off[k] + (int64_t)m_rows[k] * m_ld[k]; t.ld = (uint32_t)m_ld[k]; t.period = (uint32_t)m_period[k];
+    t.col0 = (uint32_t)m_col0[k];
+    adam_magic(t.ld, t.ld_m, t.ld_s);
+    adam_magic(t.period, t.per_m, t.per_s);
+  }
+  for (int k = 0; k < nslice; ++k) {
+    DPC_CHECK_ARG(s_off[k] >= 0 && s_rows[k] > 0 && s_ld[k] > 0 && s_col0[k] >= 0 && s_ncol[k] > 0 && s_col0[k] + s_ncol[k] <= s_ld[k] &&
+                  s_off[k] + (int64_t)s_rows[k] * s_ld[k] <= n, "adam_slices: bad slice");
+    DPC_CHECK_ARG((!s_gT[k] || s_ld_gT[k] >= s_rows[k]) && (!s_pT[k] || s_ld_pT[k] >= s_rows[k]), "adam_slices: transposed buffers need rows of at least the matrix's row count");
+    // every element of the slice must be one the flat blocks skip
+    bool owned = false;
+    for (int q = 0; q < nmat; ++q)
+      owned = owned || (s_off[k] == m_off[q] && s_rows[k] == m_rows[q] && s_ld[k] == m_ld[q] && s_col0[k] % m_period[q] >= m_col0[q] &&
+                        (s_col0[k] + s_ncol[k] - 1) % m_period[q] >= m_col0[q] && s_col0[k] / m_period[q] == (s_col0[k] + s_ncol[k] - 1) / m_period[q]);
+    DPC_CHECK_ARG(owned, "adam_slices: a slice must lie inside the cond columns of one of the matrices");
+    AdamSlice& sl = a.sl[k];
+    sl.off = s_off[k]; sl.rows = s_rows[k]; sl.ld = s_ld[k]; sl.col0 = s_col0[k]; sl.ncol = s_ncol[k]; sl.gT = s_gT[k];
+    sl.ld_gT = s_ld_gT[k]; sl.pT = s_pT[k]; sl.ld_pT = s_ld_pT[k];
+  }
+  a.nmat = nmat; a.nslice = nslice;
+  return adam_launch(a, stream);
 }
 
 // Standalone DP noise-add (+ optional clamp) over a flat buffer: x = clamp(x + scale * noise).

@@ -1081,17 +1081,27 @@ class StepEngine(object):
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
             self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=kscale)
         self._join()
-        if self.sparse_d:
+        # The cond columns' sorted row sums join the flat gradient inside the Adam launch (_disc_update) - unless no
+        # update follows, or the flat gradient is all-reduced first: then one transpose launch adds them here
+        fused = update and self._adam_slices_d()
+        if self.sparse_d and not fused:
             C, Dd, gw = self.C, self.Dd, d.G('seq.0.weight')
             ops.transpose_slices([(self.dW1cT[s * C:(s + 1) * C], gw[:, s * self.row + Dd:(s + 1) * self.row])
                                   for s in range(self.pac)], accumulate=True)
         self._probe('d_grads_done')
         if update:
-            self._disc_update(inj)
+            self._disc_update(inj, fused)
         if sub is None:
             ops.state_advance(self.rng, rng_b=self.rng_shared if update else None, t_a=self.disc.t if update else None)
 
-    def _disc_update(self, inj):
+    def _adam_slices_d(self):
+        """The discriminator's Adam launch also moves the cond slices of W1 (gradient addend in, W1cT out)."""
+        return self.sparse_d and not self.dist.active and self.pac <= 16
+
+    def _adam_slices_g(self):
+        return self.sparse_cond and not self.dist.active and self.L + 1 <= 8
+
+    def _disc_update(self, inj, fused=False):
         d = self.disc
         self._allreduce(d.g)
         seg_add, seg_off, noise_scale, noise_inj = None, None, 0.0, None
@@ -1109,9 +1119,19 @@ class StepEngine(object):
             # parameter from the stream all ranks share, scaled by the same 1/n
             noise_scale = self.dp_sigma * self.dp_clip / self.gn
             noise_inj = inj.get('dp_noise')
-        ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, clamp=self.weight_clip if self.private else 0.0,
-                      t_dev=d.t, t_host=1 + self._k, seg_off=seg_off, seg_add=seg_add, noise_scale=noise_scale,
-                      noise_inj=noise_inj, rng=self.rng_shared, site=ops.SITE_NOISE_D + self._so)
+        kw = dict(clamp=self.weight_clip if self.private else 0.0, t_dev=d.t, t_host=1 + self._k, seg_off=seg_off,
+                  seg_add=seg_add, noise_scale=noise_scale, noise_inj=noise_inj, rng=self.rng_shared,
+                  site=ops.SITE_NOISE_D + self._so)
+        if fused:
+            # one launch: the cond slices of W1 (pac of them, periodic in the pac-row layout) take their transposed
+            # gradient addend and leave their updated values in W1cT - two transpose launches less on the main stream
+            W1, C, Dd, row = d.P('seq.0.weight'), self.C, self.Dd, self.row
+            ops.adam_step_slices(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, [(W1, row, Dd)],
+                                 [(W1, s * row + Dd, C, self.dW1cT[s * C:(s + 1) * C], self.W1cT[s * C:(s + 1) * C])
+                                  for s in range(self.pac)], **kw)
+            d.loaded = False
+            return
+        ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, **kw)
         if self.sparse_d:
             self._refresh_w1ct()
 
@@ -1234,18 +1254,28 @@ class StepEngine(object):
         self._gen_bias_grads(self.part)
         self._join()
         self._probe('g_grads_done')
-        if self.sparse_cond and not self.deterministic:
-            # the scattered cond-column gradients into their places in the flat gradient buffer
+        fused = update and self._adam_slices_g()
+        if self.sparse_cond and not self.deterministic and not fused:
+            # the scattered cond-column gradients into their places in the flat gradient buffer (inside the Adam
+            # launch when an update follows and nothing all-reduces the flat gradient first: _gen_update)
             ops.transpose_slices([(self.dWcT[l], self.gen.G('seq.%d.fc.weight' % l if l < L else 'seq.%d.weight' % L)[:, -self.C:])
                                   for l in range(L + 1)])
         if update:
-            self._gen_update()
+            self._gen_update(fused)
         if sub is None:
             ops.state_advance(self.rng, t_a=self.gen.t if update else None)
 
-    def _gen_update(self):
+    def _gen_update(self, fused=False):
         g = self.gen
         self._allreduce(g.g)
+        if fused:
+            Ws = [self._gen_weight(l) for l in range(self.L + 1)]
+            grads = self.dWcT if not self.deterministic else [None] * (self.L + 1)
+            ops.adam_step_slices(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, [(W, W.shape[1], W.shape[1] - self.C) for W in Ws],
+                                 [(W, W.shape[1] - self.C, self.C, grads[l], self.WcT[l]) for l, W in enumerate(Ws)],
+                                 t_dev=g.t)
+            self._wct_stale = False
+            return
         ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
         self._refresh_wct()
 

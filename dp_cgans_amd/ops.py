@@ -588,6 +588,37 @@ def adam_step(p, g, m, v, lr, wd, b1=0.5, b2=0.9, eps=1e-8, clamp=0.0, gscale=1.
                t_host, _p(seg_off), _p(seg_add), nseg, noise_scale, _p(noise_inj), _p(rng), site, _stream())
 
 
+def adam_step_slices(p, g, m, v, lr, wd, mats, slices, b1=0.5, b2=0.9, eps=1e-8, clamp=0.0, gscale=1.0, t_dev=None,
+                     t_host=1, seg_off=None, seg_add=None, noise_scale=0.0, noise_inj=None, rng=None, site=SITE_NOISE_D):
+    """adam_step over a flat buffer with cond slices (dpc_adam_step_slices).  mats: [(W, period, col0)] with W a
+    [rows, ld] view INTO p whose columns c with c % period >= col0 are cond columns; slices: [(W, col0, ncol, gT, pT)]
+    - columns [col0, col0 + ncol) of W, gT / pT the transposed gradient addend / parameter copy [ncol, >= rows]
+    (either may be None)."""
+    def off(W):
+        o = (W.data_ptr() - p.data_ptr()) // 4
+        if o < 0 or o + W.shape[0] * W.shape[1] > p.numel() or not W.is_contiguous():
+            raise ValueError('adam_step_slices: matrices must be contiguous views into p')
+        return o
+    nm, ns = len(mats), len(slices)
+    I64m, I32m = ctypes.c_int64 * max(nm, 1), ctypes.c_int * max(nm, 1)
+    I64s, I32s, Ps = ctypes.c_int64 * max(ns, 1), ctypes.c_int * max(ns, 1), ctypes.c_void_p * max(ns, 1)
+    for _, _, _, gT, pT in slices:
+        _chk(gT, torch.float32, 'gT')
+        _chk(pT, torch.float32, 'pT')
+    nseg = seg_add.shape[0] if seg_add is not None else 0
+    lib().call('dpc_adam_step_slices', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, wd, clamp, gscale, _p(t_dev),
+               t_host, _p(seg_off), _p(seg_add), nseg, noise_scale, _p(noise_inj), _p(rng), site,
+               nm, I64m(*[off(W) for W, _, _ in mats]), I32m(*[W.shape[0] for W, _, _ in mats]),
+               I32m(*[W.shape[1] for W, _, _ in mats]), I32m(*[int(pe) for _, pe, _ in mats]), I32m(*[int(c0) for _, _, c0 in mats]),
+               ns, I64s(*[off(W) for W, _, _, _, _ in slices]), I32s(*[W.shape[0] for W, _, _, _, _ in slices]),
+               I32s(*[W.shape[1] for W, _, _, _, _ in slices]), I32s(*[int(c0) for _, c0, _, _, _ in slices]),
+               I32s(*[int(nc) for _, _, nc, _, _ in slices]),
+               Ps(*[(gT.data_ptr() if gT is not None else None) for _, _, _, gT, _ in slices]),
+               I64s(*[(_ld(gT) if gT is not None else 0) for _, _, _, gT, _ in slices]),
+               Ps(*[(pT.data_ptr() if pT is not None else None) for _, _, _, _, pT in slices]),
+               I64s(*[(_ld(pT) if pT is not None else 0) for _, _, _, _, pT in slices]), _stream())
+
+
 def noise_add_clamp(x, scale, noise_inj=None, rng=None, site=SITE_NOISE_D, clamp=0.0):
     lib().call('dpc_noise_add_clamp', _p(x), x.numel(), scale, _p(noise_inj), _p(rng), site, clamp, _stream())
     return x

@@ -398,6 +398,24 @@ int dpc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float eps, float wd, float clamp, float gscale, const int32_t* t_dev, int t_host,
                   const int64_t* seg_off, const float* seg_add, int nseg, float noise_scale,
                   const float* noise_inj, const uint64_t* rng, uint32_t site, void* stream);
+/* The same step over a parameter buffer whose matrices hold COND SLICES - columns that multiply a two-hot cond vector
+ * (the generator's Linears over cat([.., cond]), dp_cgan.py:83,606; the discriminator's first Linear over pac
+ * sub-rows [data | cond], :66-68,622-623) - in ONE launch instead of dpc_transpose_slices + dpc_adam_step +
+ * dpc_transpose_slices.  Slice k = columns [s_col0[k], s_col0[k] + s_ncol[k]) of the matrix of s_rows[k] rows of
+ * length s_ld[k] at flat offset s_off[k]: its gradient takes the transposed addend s_gT[k] [ncol][s_ld_gT[k]]
+ * (nullable: the sorted row sums of dpc_hot_rows_sum; the sum is written back to g) and its updated parameters are
+ * also written transposed to s_pT[k] [ncol][s_ld_pT[k]] (nullable: W[:, cond]^T, the row-gather table of the forward).
+ * The nmat (<= 8) matrices that own the nslice (<= 16) slices: flat offset m_off, m_rows rows of length m_ld; their
+ * cond columns are those with (column mod m_period) >= m_col0.  All table arguments are HOST arrays.  Same
+ * arithmetic, segment lookup and noise draw per element as dpc_adam_step. */
+int dpc_adam_step_slices(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                         float eps, float wd, float clamp, float gscale, const int32_t* t_dev, int t_host,
+                         const int64_t* seg_off, const float* seg_add, int nseg, float noise_scale,
+                         const float* noise_inj, const uint64_t* rng, uint32_t site, int nmat,
+                         const int64_t* m_off, const int* m_rows, const int* m_ld, const int* m_period,
+                         const int* m_col0, int nslice, const int64_t* s_off, const int* s_rows,
+                         const int* s_ld, const int* s_col0, const int* s_ncol, const float* const* s_gT,
+                         const int64_t* s_ld_gT, float* const* s_pT, const int64_t* s_ld_pT, void* stream);
 /* x = clamp(x + scale * noise): the stand-alone DP noise-add (+ weight clamp) kernel */
 int dpc_noise_add_clamp(float* x, int64_t n, float scale, const float* noise_inj, const uint64_t* rng,
                         uint32_t site, float clamp, void* stream);

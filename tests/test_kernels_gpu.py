@@ -363,6 +363,61 @@ def test_adam_matches_reference_trace(ops, name):
         close(p1, p2.clamp(-0.01, 0.01), what='fused segment noise + clamp')
 
 
+@pytest.mark.parametrize('noise', ['none', 'philox', 'injected'])
+@pytest.mark.parametrize('rows_g, rows_d', [(70, 40), (32, 64), (5, 33)])
+def test_adam_with_cond_slices_equals_transposes_around_the_plain_step(ops, noise, rows_g, rows_d):
+    """dpc_adam_step_slices against dpc_transpose_slices (gradient addend in) + dpc_adam_step + dpc_transpose_slices
+    (updated cond columns out): bit-identical parameters, moments, completed gradient and transposed copies - a
+    generator-like matrix with one trailing cond slice and a discriminator-like one with pac = 2 periodic slices,
+    beside tensors without slices, with hook segments, clamp and the three noise sources."""
+    d_ = dev()
+    g_ = torch.Generator().manual_seed(rows_g * 100 + rows_d + len(noise))
+    shapes = [(7,), (rows_g, 45), (11,), (rows_d, 52), (3,)]
+    offs, n = [], 0
+    for sh in shapes:
+        offs.append(n)
+        n += (int(np.prod(sh)) + 3) // 4 * 4
+    mk = lambda scale=1.0: (torch.randn(n, generator=g_) * scale).to(d_)
+    p0, g0, m0, v0 = mk(0.02), mk(0.01), mk(0.001), mk(0.001).abs()
+    view = lambda buf, k: buf[offs[k]:offs[k] + int(np.prod(shapes[k]))].view(shapes[k])
+    # slices: (matrix index, first column, columns)
+    sl = [(1, 30, 15), (3, 17, 9), (3, 43, 9)]
+    gTs = [(torch.randn(nc, shapes[k][0] + 3, generator=g_) * 0.01).to(d_)[:, :shapes[k][0]] for k, c0, nc in sl]
+    seg_off = torch.tensor(offs + [n], dtype=torch.int64, device=d_)
+    seg_add = (torch.randn(len(shapes), generator=g_) * 0.005).to(d_)
+    rng = ops.new_rng(77, d_)
+    t_dev = torch.full((1,), 3, dtype=torch.int32, device=d_)
+    kw = dict(clamp=0.05, t_dev=t_dev, t_host=2, seg_off=seg_off, seg_add=seg_add, gscale=0.5)
+    if noise == 'philox':
+        kw.update(noise_scale=0.003, rng=rng, site=ops.SITE_NOISE_D + 64)
+    elif noise == 'injected':
+        kw.update(noise_scale=0.003, noise_inj=mk())
+    # reference: three launches
+    p2, g2, m2, v2 = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    ops.transpose_slices([(gT, view(g2, k)[:, c0:c0 + nc]) for (k, c0, nc), gT in zip(sl, gTs)], accumulate=True)
+    ops.adam_step(p2, g2, m2, v2, 2e-4, 1e-6, **kw)
+    pT2 = [torch.full((nc, shapes[k][0] + 1), 9.0, device=d_)[:, :shapes[k][0]] for k, c0, nc in sl]
+    ops.transpose_slices([(view(p2, k)[:, c0:c0 + nc], pT) for (k, c0, nc), pT in zip(sl, pT2)])
+    # one launch
+    p1, g1, m1, v1 = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    pT1 = [torch.full((nc, shapes[k][0] + 1), 9.0, device=d_)[:, :shapes[k][0]] for k, c0, nc in sl]
+    mats = [(view(p1, 1), 45, 30), (view(p1, 3), 26, 17)]
+    ops.adam_step_slices(p1, g1, m1, v1, 2e-4, 1e-6, mats,
+                         [(view(p1, k), c0, nc, gT, pT) for (k, c0, nc), gT, pT in zip(sl, gTs, pT1)], **kw)
+    for a, b, what in ((p1, p2, 'p'), (g1, g2, 'g'), (m1, m2, 'm'), (v1, v2, 'v')):
+        assert torch.equal(a, b), what
+    for a, b in zip(pT1, pT2):
+        assert torch.equal(a, b)
+    assert not torch.equal(p1, p0)
+    # without an addend and without a copy the slices still take the plain update
+    p3, g3, m3, v3 = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    ops.adam_step(p3, g3, m3, v3, 2e-4, 1e-6, **kw)
+    p4, g4, m4, v4 = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    mats = [(view(p4, 1), 45, 30), (view(p4, 3), 26, 17)]
+    ops.adam_step_slices(p4, g4, m4, v4, 2e-4, 1e-6, mats, [(view(p4, k), c0, nc, None, None) for k, c0, nc in sl], **kw)
+    assert torch.equal(p3, p4) and torch.equal(m3, m4) and torch.equal(v3, v4) and torch.equal(g4, g0)
+
+
 # ------------------------------------------------------------------------------------------------
 # activation + cond loss
 # ------------------------------------------------------------------------------------------------
