@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--table', default='T1M')
     ap.add_argument('--rows', type=int, default=None, help='override the number of table rows (debug)')
     ap.add_argument('--batch', type=int, default=8192)
