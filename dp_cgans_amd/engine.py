@@ -1084,7 +1084,7 @@ class StepEngine(object):
         # The cond columns' sorted row sums join the flat gradient inside the Adam launch (_disc_update) - unless no
         # update follows, or the flat gradient is all-reduced first: then one transpose launch adds them here
         fused = update and self._adam_slices_d()
-        if self.sparse_d and not fused:
+        if self.sparse_d and (not fused or self.dist.active):
             C, Dd, gw = self.C, self.Dd, d.G('seq.0.weight')
             ops.transpose_slices([(self.dW1cT[s * C:(s + 1) * C], gw[:, s * self.row + Dd:(s + 1) * self.row])
                                   for s in range(self.pac)], accumulate=True)
@@ -1096,10 +1096,10 @@ class StepEngine(object):
 
     def _adam_slices_d(self):
         """The discriminator's Adam launch also moves the cond slices of W1 (gradient addend in, W1cT out)."""
-        return self.sparse_d and not self.dist.active and self.pac <= 16
+        return self.sparse_d and self.pac <= 16
 
     def _adam_slices_g(self):
-        return self.sparse_cond and not self.dist.active and self.L + 1 <= 8
+        return self.sparse_cond and self.L + 1 <= 8
 
     def _disc_update(self, inj, fused=False):
         d = self.disc
@@ -1126,9 +1126,11 @@ class StepEngine(object):
             # one launch: the cond slices of W1 (pac of them, periodic in the pac-row layout) take their transposed
             # gradient addend and leave their updated values in W1cT - two transpose launches less on the main stream
             W1, C, Dd, row = d.P('seq.0.weight'), self.C, self.Dd, self.row
+            # (data parallel: the addend went into the flat gradient before its all-reduce, _d_back; the launch
+            # still writes W1cT)
             ops.adam_step_slices(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, [(W1, row, Dd)],
-                                 [(W1, s * row + Dd, C, self.dW1cT[s * C:(s + 1) * C], self.W1cT[s * C:(s + 1) * C])
-                                  for s in range(self.pac)], **kw)
+                                 [(W1, s * row + Dd, C, None if self.dist.active else self.dW1cT[s * C:(s + 1) * C],
+                                   self.W1cT[s * C:(s + 1) * C]) for s in range(self.pac)], **kw)
             d.loaded = False
             return
         ops.adam_step(d.p, d.g, d.m, d.v, self.lr_d, self.wd_d, **kw)
@@ -1255,7 +1257,7 @@ class StepEngine(object):
         self._join()
         self._probe('g_grads_done')
         fused = update and self._adam_slices_g()
-        if self.sparse_cond and not self.deterministic and not fused:
+        if self.sparse_cond and not self.deterministic and (not fused or self.dist.active):
             # the scattered cond-column gradients into their places in the flat gradient buffer (inside the Adam
             # launch when an update follows and nothing all-reduces the flat gradient first: _gen_update)
             ops.transpose_slices([(self.dWcT[l], self.gen.G('seq.%d.fc.weight' % l if l < L else 'seq.%d.weight' % L)[:, -self.C:])
@@ -1270,7 +1272,7 @@ class StepEngine(object):
         self._allreduce(g.g)
         if fused:
             Ws = [self._gen_weight(l) for l in range(self.L + 1)]
-            grads = self.dWcT if not self.deterministic else [None] * (self.L + 1)
+            grads = self.dWcT if not (self.deterministic or self.dist.active) else [None] * (self.L + 1)
             ops.adam_step_slices(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, [(W, W.shape[1], W.shape[1] - self.C) for W in Ws],
                                  [(W, W.shape[1] - self.C, self.C, grads[l], self.WcT[l]) for l, W in enumerate(Ws)],
                                  t_dev=g.t)
