@@ -164,19 +164,22 @@ __device__ __forceinline__ double condvec_readlane_f64(double v, int l) {
 __device__ __forceinline__ void condvec_pair_wave(const CondvecArgs& a, const int64_t b, const int lane) {
   int i, j;
   double r;
+  // draws 4b .. 4b+3 of the site are ONE Philox block (dpc_draw_u32 would compute it four times over)
+  DpcPhilox4 ph = {{0u, 0u, 0u, 0u}};
+  if (!a.pairs_inj || !a.r_inj) ph = dpc_philox(a.rng[0], a.rng[1], a.site, (uint64_t)b);
   if (a.pairs_inj) {
     i = a.pairs_inj[2 * b];
     j = a.pairs_inj[2 * b + 1];
   } else {
     // ordered draw of two distinct columns (np.random.choice(nd, 2, replace=False) in distribution)
-    float u1 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b));
-    float u2 = dpc_u32_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 1));
+    float u1 = dpc_u32_to_unit(ph.v[0]);
+    float u2 = dpc_u32_to_unit(ph.v[1]);
     i = min(a.nd - 1, (int)(u1 * a.nd));
     j = min(a.nd - 2, (int)(u2 * (a.nd - 1)));
     if (j >= i) ++j;
   }
   if (a.r_inj) r = a.r_inj[b];
-  else r = dpc_u64_to_unit(dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 2), dpc_draw_u32(a.rng, a.site, 4 * (uint64_t)b + 3));
+  else r = dpc_u64_to_unit(ph.v[2], ph.v[3]);
   const int lo = min(i, j), hi = max(i, j);
   const int ka = a.dims[lo], kb = a.dims[hi], sa = a.cond_st[lo], sb = a.cond_st[hi];
   // the pair's joint values in ascending packed-code order = (va desc, vb desc): entry p is
