@@ -642,6 +642,14 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
   float bias4[4], aux4[4], c_old[4];
   uint8_t kp[4];
   const bool ld_keep = g.epi == EPI_LEAKY_DROPOUT && g.keep != nullptr;
+  // own keep bits: the thread's four columns are one Philox block when their flat index row * N + col starts on a
+  // multiple of 4 (N % 4 == 0: every layer width in practice) - one block instead of four
+  uint32_t kw[4] = {0u, 0u, 0u, 0u};
+  const bool quad = g.epi == EPI_LEAKY_DROPOUT && !g.keep && (g.N & 3) == 0 && n0 + c4 + 3 < g.N;
+  if (quad) {
+    const DpcPhilox4 ph = dpc_philox(g.rng[0], g.rng[1], g.site, ((uint64_t)row * g.N + n0 + c4) >> 2);
+    kw[0] = ph.v[0]; kw[1] = ph.v[1]; kw[2] = ph.v[2]; kw[3] = ph.v[3];
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int colc = min(n0 + c4 + q, g.N - 1);
@@ -659,6 +667,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
     if (g.epi == EPI_LEAKY_DROPOUT) {
       float keep;
       if (g.keep) keep = kp[q] ? 1.f : 0.f;
+      else if (quad) keep = (kw[q] >> 31) ? 1.f : 0.f;
       else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
       const float slope = (x > 0.f ? 1.f : g.leak) * keep * 2.f;
       g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
