@@ -257,11 +257,13 @@ def step_kernel_rooflines(eng, eager_step, args):
             'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
             'kernel': 'persample_gram_all_kernel', 'examples': n, 'algorithmic_bytes': by, 'launch_us': us,
             'in_graph_trace': None if not t else {'achieved': t['achieved'], 'frac': t['frac'], 'avg_launch_us': t['avg_us']}}
-    adam = [e for e in log if e[0] == 'dpc_adam_step']
+    adam = [e for e in log if e[0] in ('dpc_adam_step', 'dpc_adam_step_slices')]
     if adam and eng.dp_mode == 'dpsgd':
         dsc = eng.disc
         saved = [x.clone() for x in (dsc.p, dsc.m, dsc.v, dsc.t)]
         by = 28.0 * dsc.n                               # p, g, m, v read; p, m, v written; the noise is drawn in registers
+        if adam[0][0].endswith('_slices'):              # + the cond slices' transposed gradient addend in and copy out
+            by += 8.0 * eng.pac * eng.C * eng.ddim[0]
         us = timed(adam[:1], copies=20)
         for x, y in zip((dsc.p, dsc.m, dsc.v, dsc.t), saved):
             x.copy_(y)
@@ -270,7 +272,7 @@ def step_kernel_rooflines(eng, eager_step, args):
         t = tk.get('adam_kernel_disc')
         res['dp_noise_in_step'] = {
             'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-            'kernel': 'adam_kernel<true> (Gaussian noise add fused into the discriminator Adam step)',
+            'kernel': 'adam_kernel<true> (Gaussian noise add fused into the discriminator Adam step; with the cond slices of W1 moved in the same launch)',
             'parameters': dsc.n, 'algorithmic_bytes': by, 'launch_us': us,
             'in_graph_trace': None if not t else {'achieved': t['achieved'], 'frac': t['frac'], 'avg_launch_us': t['avg_us']}}
     eng.Zp.zero_()               # the replayed first-layer products added into it

@@ -53,8 +53,9 @@ def algorithmic_bytes_per_step(c):
         'activate_fwd_small_kernel<true>': 12.0 * B * Dd,                 # + the cond loss gradient written
         'activate_bwd_tiled_kernel<true>': 16.0 * B * Dd,                 # y, dy, loss gradient in; d raw out
         'persample_gram_all_kernel': clip,
-        'adam_kernel_disc': 28.0 * c['disc_params'],
-        'adam_kernel_gen': 28.0 * c['gen_params'],
+        # (+ the cond slices' transposed gradient addend in and transposed copy out, moved by the same launch)
+        'adam_kernel_disc': 28.0 * c['disc_params'] + 8.0 * pac * C * d[0],
+        'adam_kernel_gen': 28.0 * c['gen_params'] + 8.0 * C * (sum(g) + Dd),
         'row_gather_kernel': 8.0 * B * Dd,
         'bn_relu_fwd_fused_kernel': 2 * sum(8.0 * B * w for w in g),     # both generator forwards of the step
         'bn_relu_bwd_fused_kernel': sum(16.0 * B * w for w in g),
