@@ -41,19 +41,52 @@ def main():
     ap.add_argument('--serial', action='store_true', help='no side streams: the step is one chain of kernels (tuning)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--devices', default=None,
+                    help='GPU index of each local rank, comma separated (default: local rank r computes on GPU r); '
+                         '"0,0" rehearses two ranks on one GPU (then over gloo: RCCL needs a GPU per rank)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launch plumbing only: the ranks form their process group, meet at a barrier, agree on a '
+                         'number and rank 0 prints a JSON line - no GPU is touched (runs on a CPU-only host over gloo)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Started directly (`python bench.py --gpus N`): this process becomes the launcher.  It starts one fresh
+        # child per GPU BEFORE anything here has touched the GPU (torch is not even imported yet), relays rank 0's
+        # JSON line and exits with the first non-zero child status.
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
+    from dp_cgans_amd.parallel import Dist
+
+    if args.dry_run:
+        os.environ.setdefault('DPCGAN_DIST_BACKEND', 'gloo')
+    dev_index = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.devices:
+        devs = [int(x) for x in args.devices.split(',')]
+        if len(devs) != args.gpus:
+            raise SystemExit('--devices names %d GPUs for %d ranks' % (len(devs), args.gpus))
+        dev_index = devs[dev_index]
+        if len(set(devs)) < len(devs):
+            os.environ.setdefault('DPCGAN_DIST_BACKEND', 'gloo')      # ranks sharing a GPU cannot form an RCCL group
+    dist = Dist(device='cpu' if args.dry_run else 'cuda:%d' % dev_index)
+    if dist.world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d: run it directly (it starts its own ranks) '
+                         'or under torch.distributed.run --nproc-per-node %d' % (args.gpus, dist.world, args.gpus))
+    if args.dry_run:
+        dist.barrier()
+        agreed = dist.max_float(float(dist.rank), 'cpu')
+        ok = agreed == float(dist.world - 1)
+        dist.barrier()
+        if dist.rank == 0:
+            print(json.dumps({'dry_run': True, 'n_gpus': dist.world, 'backend': dist.backend, 'max_rank_seen': agreed}))
+        dist.shutdown()
+        raise SystemExit(0 if ok else 1)
+
     from dp_cgans_amd.data_sampler import DataSampler
     from dp_cgans_amd.engine import GraphStep, StepEngine
-    from dp_cgans_amd.parallel import Dist
     from dp_cgans_amd.synthetic import build_encoded_table
 
-    dist = Dist()
-    if dist.world != args.gpus:
-        if args.gpus != 1 or dist.world != 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d seen)' % (args.gpus, dist.world))
-    dev = torch.device('cuda', dist.local_rank)
+    dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
     dims = tuple(int(x) for x in args.dims.split(','))
 
@@ -121,6 +154,51 @@ def main():
     if dist.rank == 0:
         print(json.dumps(out))
     dist.shutdown()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started directly: N child processes of this same command line, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set; the children
+    see WORLD_SIZE and run as ranks).  The launcher itself never initialises the GPU - no torch import, no HIP call -
+    and nothing is exec'ed: children are fresh processes.  Rank 0's stdout (the ONE JSON line) is relayed; the other
+    ranks' stdout is dropped, every rank's stderr passes through.  If a rank fails, the others are ended (they would
+    wait for it in the next collective) and its exit status is returned."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL's intra-node transport needs here
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc, out0 = 0, None
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            try:
+                if r == 0 and out0 is None:
+                    out0, _ = procs[0].communicate(timeout=0.2)
+                else:
+                    procs[r].wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            live.discard(r)
+            if procs[r].returncode != 0 and rc == 0:
+                rc = procs[r].returncode
+                sys.stderr.write('bench.py: rank %d exited with status %d; ending the other ranks\n' % (r, rc))
+                for q in sorted(live):
+                    procs[q].terminate()         # exactly the processes started above
+    # rank 0's stdout carries the JSON line - and whatever a library chose to print there (gloo announces its
+    # connections on stdout): only the JSON goes to this command's stdout, the rest to stderr
+    for line in (out0 or '').splitlines():
+        (sys.stdout if line.lstrip().startswith('{') else sys.stderr).write(line + '\n')
+    sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
 
 
 def source_sha():

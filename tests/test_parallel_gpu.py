@@ -79,3 +79,22 @@ def test_rccl_single_rank_default_step_with_fused_statistics(mode):
 @pytest.mark.parametrize('mode', ['dpsgd'])
 def test_two_ranks_default_step_with_fused_statistics(mode):
     launch(['fused', mode])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` started directly: the launcher's two children share cuda:0 here (over gloo), run the
+    timed graph-replayed step and rank 0's JSON line comes back through the launcher."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--devices', '0,0', '--rows', '20000',
+                        '--batch', '512', '--dims', '64,64', '--steps', '3', '--warmup', '2', '--no-roofline',
+                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=400, cwd=root)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['value'] > 0 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 1024 and rec['config']['parallelism'] == 'dp2'
+    assert 'eager all-reduces between them' in rec['config']['launch']      # gloo: graph segments cut at the collectives
