@@ -88,6 +88,27 @@ __device__ __forceinline__ float gemm_gather2(const GemmArgs& g, int row, int co
 
 constexpr int BK = 32;
 
+// Measurement build only (tools/gemm_stamp.sh compiles this file with -DDPC_GEMM_STAMP into a library of its own; the
+// product library never carries it): thread 0 of every block of gemm_f32_kernel leaves the shader-cycle counter
+// at five points of the block's life - and the 100 MHz wall clock at its two ends - in a caller-provided buffer.
+#ifdef DPC_GEMM_STAMP
+__device__ unsigned long long* dpc_stamp_buf = nullptr;
+#define DPC_STAMP(i)                                                                                 \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && dpc_stamp_buf) dpc_stamp_buf[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define DPC_STAMP_WALL(i)                                                                            \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && dpc_stamp_buf) dpc_stamp_buf[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+  } while (0)
+extern "C" int dpc_debug_stamp_buffer(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(dpc_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#else
+#define DPC_STAMP(i) do {} while (0)
+#define DPC_STAMP_WALL(i) do {} while (0)
+#endif
+
 // One operand's staging of a BMN x BK tile: global -> registers (float4) -> LDS.
 //   KC  (k contiguous in global: stride_mn = leading dimension): LDS image [mn][BK + 4].  A thread
 //       moves 4 consecutive k of one row with one 16-byte load and one ds_write_b128; a lane reads
@@ -145,8 +166,11 @@ struct Stage {
         const float* src = base + (int64_t)min(row, mlast) * ld;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = src[min(k + j, klast)];
-          e[j] = (row <= mlast && k + j <= klast) ? v : 0.f;
+          // (masked with AND, not `cond ? v : 0`: hipcc turns a select whose operand is a load into a branch around
+          // the load and drains vmcnt at the join - sixteen dependent round trips for one partial tile, ~5 us)
+          const float v = src[min(k + j, klast)];
+          const uint32_t keep = (row <= mlast && k + j <= klast) ? 0xffffffffu : 0u;
+          e[j] = __uint_as_float(__float_as_uint(v) & keep);
         }
       } else {
         constexpr int TPR = BMN / 4;            // threads per k-row
@@ -156,8 +180,9 @@ struct Stage {
         const float* src = base + (int64_t)min(k, klast) * ld;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = src[min(mn + j, mlast)];
-          e[j] = (k <= klast && mn + j <= mlast) ? v : 0.f;
+          const float v = src[min(mn + j, mlast)];
+          const uint32_t keep = (k <= klast && mn + j <= mlast) ? 0xffffffffu : 0u;
+          e[j] = __uint_as_float(__float_as_uint(v) & keep);
         }
         if (KS) sc[p] = ks[min(k, klast)];
       }
@@ -216,13 +241,19 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
   const int li = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[TM][TN];
+  // Accumulator chains.  Back-to-back v_mfma_f32_32x32x2_f32 on ONE accumulator issue every ~96 cycles, not 64 (SQ
+  // counters of a lone 64x64 block: MFMA-busy exactly 64 cycles per instruction, but 1546 wave-cycles per 16-MFMA
+  // K-tile, 70 % of them SQ_WAIT_INST_ANY - the dependent-accumulator latency).  A wave that owns a single 32x32
+  // tile therefore keeps TWO chains (even and odd k-steps) and adds them before the epilogue; with 2 x 2 tiles
+  // per wave the four tiles' chains interleave already.
+  constexpr int CH = (TM * TN == 1) ? 2 : 1;
+  f32x16 acc[TM][TN], acc2[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
   const int64_t lda = A_KC ? g.a_rs : g.a_cs;
   const int64_t ldb = B_KC ? g.b_cs : g.b_rs;
@@ -262,7 +293,10 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            if (CH == 2 && (s & 1))
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc2[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -305,6 +339,39 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     }
   }
 
+  // Main pipeline over the nfull full K-tiles.  The MFMA chain of a wave never waits for LDS or for the barrier:
+  //   * all FOUR fragment groups of a K-tile (8 k each) live in registers (fr[0..3]: 8 VGPRs per group and 32 x 32
+  //     MFMA tile pair), read from LDS one half-iteration before their MFMAs issue;
+  //   * the ONE barrier of an iteration sits in its middle.  Iteration t: global loads of tile t+2 -> registers;
+  //     tile t+1 (loaded an iteration ago) registers -> LDS buffer (t+1)&1; MFMAs of groups 0, 1; barrier (now tile
+  //     t+1 is visible and every wave holds all of tile t in registers); fragment groups 0, 1 of tile t+1 -> the
+  //     registers groups 0, 1 just vacated; MFMAs of groups 2, 3; fragment groups 2, 3 of tile t+1.
+  //   Buffer (t+1)&1 last held tile t-1, whose fragment reads every wave finished before the barrier of
+  //   iteration t-1 - so the store at the top of iteration t is safe with two buffers.
+  // (Before: fragments were read right after the barrier, group by group, and each K-tile paid one exposed LDS
+  // round trip behind the barrier and another between groups - 0.61 us per K-tile for 0.49 us of MFMA issue.)
+  // Strictly branch-free inside (loads past the end are clamped to the last tile, the stores and fragment reads
+  // of the last iteration are redundant, not guarded), so hipcc keeps counted s_waitcnt vmcnt(N).
+  struct Frag { float a[TM][4]; float b[TN][4]; };
+  Frag fr[4];
+  auto read_group = [&](const int gi, const float* as, const float* bs) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) SA::frag(as, wm0 + i * 32, gi * 8, li, lk, fr[gi].a[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) SB::frag(bs, wn0 + j * 32, gi * 8, li, lk, fr[gi].b[j]);
+  };
+  auto mfma_group = [&](const int gi) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (CH == 2 && (s & 1))
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[gi].a[i][s], fr[gi].b[j][s], acc2[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[gi].a[i][s], fr[gi].b[j][s], acc[i][j], 0, 0, 0);
+  };
   if (nfull > 0) {
     const int last = nfull - 1;
 #pragma unroll
@@ -315,35 +382,90 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     sa[0].store(As0);
     sb[0].store(Bs0);
     __syncthreads();
-    for (int t0 = 0; t0 < nmain; t0 += PF) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int cur = u & 1;              // PF is even, so t & 1 == u & 1
-        const int tl = min(t0 + u + PF, last);
-        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);
-        sb[u].load_fast(Bk(k_begin + tl * BK), ldb, n0, k_begin + tl * BK, g.N);
-        compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
-        sa[(u + 1) % PF].store(As + (cur ^ 1) * SA::SIZE);
-        sb[(u + 1) % PF].store(Bs + (cur ^ 1) * SB::SIZE);
-        __syncthreads();
-      }
+    for (int gi = 0; gi < 3; ++gi) read_group(gi, As0, Bs0);      // (group 3 at the top of the tile's own iteration)
+    DPC_STAMP(1);                                   // first tile in LDS, its fragments requested
+    static_assert(PF == 2, "the pipelined loop keeps two register stages (tile t+1 awaiting its LDS store, tile t+2 in flight)");
+    // The tile the next iteration loads, and - for a B whose K axis is segment-mapped (Bk above) - its offset, kept
+    // as running values: the division inside Bk() was a block of its own in the middle of every iteration.
+    int tl = min(2, last);
+    const bool seg_k = B_KC && g.seg_b == 1;
+    const int seg_pad_k = seg_k ? g.seg_pad : 0x40000000;
+    const int64_t seg_jump = seg_k ? g.seg_stride - g.seg_pad : 0;
+    int64_t tl_delta = seg_k ? gemm_seg_delta(g, k_begin + tl * BK) : 0;
+    int tl_kin = seg_k ? (k_begin + tl * BK) % g.seg_pad : 0;
+    // Issue order inside an iteration.  One wave per SIMD hides NOTHING behind its own MFMAs unless the other
+    // instructions sit BETWEEN them: hipcc's own schedule put the sixteen MFMAs of a K-tile back to back and the
+    // loads, LDS stores and fragment reads in clusters between the groups, and the SQ counters of a lone block
+    // then show the issue time of those clusters added to the MFMA time (1024 MFMA-busy cycles + ~290 issuing other
+    // instructions + ~180 parked = 1546 per K-tile).  The iteration is therefore written as four quarters, each the
+    // four (sixteen) MFMAs of one fragment group with the memory instructions that may run beside them, fenced by
+    // sched_barrier and interleaved by sched_group_barrier:
+    //   Q0  MFMAs of group 0 | fragment group 3 of THIS tile <- LDS, global loads of tile t+2
+    //   Q1  MFMAs of group 1 | tile t+1 registers -> LDS
+    //   ---- barrier ----
+    //   Q2  MFMAs of group 2 | fragment groups 0, 1 of tile t+1 <- LDS (into the registers Q0, Q1 vacated)
+    //   Q3  MFMAs of group 3 | fragment group 2 of tile t+1 <- LDS
+    // Every fragment group is read at least eight MFMAs (512 cycles) before its own MFMAs issue.
+    constexpr int NM = 4 * TM * TN;                                   // MFMAs per quarter
+    constexpr int N_VM = SA::PASSES * (KS ? 2 : 1) + SB::PASSES;      // global loads per K-tile (KS: + the k-scales)
+    constexpr int N_DW = SA::PASSES + SB::PASSES;                     // LDS stores per K-tile
+    constexpr int N_DRG = TM * (A_KC ? 1 : 4) + TN * (B_KC ? 1 : 4);  // LDS reads per fragment group
+#define DPC_PIPE(MASK_FIRST, N_FIRST, MASK, N)                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) {                                                  \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+      if (i_ == 0 && (N_FIRST) > 0) __builtin_amdgcn_sched_group_barrier(MASK_FIRST, N_FIRST, 0);         \
+      if (i_ * (((N) + NM - 1) / NM) < (N)) __builtin_amdgcn_sched_group_barrier(MASK, ((N) + NM - 1) / NM, 0); \
     }
-    // The nfull - nmain (< PF) full tiles left over are in the ring already - the last pass above (or
-    // the prologue, when there was none) loaded them, and tile nmain sits in LDS buffer 0: they are
-    // consumed from there, still pipelined (they used to take the serial path below, ~3 us a tile).
-    const int rem = nfull - nmain;
+    for (int t0 = 0; t0 + 1 < nfull; t0 += 2) {
 #pragma unroll
-    for (int u = 0; u + 1 < PF; ++u) {
-      if (u < rem) {
-        const int cur = u & 1;
-        compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
-        if (u + 1 < rem) {
-          sa[u + 1].store(As + (cur ^ 1) * SA::SIZE);
-          sb[u + 1].store(Bs + (cur ^ 1) * SB::SIZE);
+      for (int u = 0; u < 2; ++u) {
+        const int nxt = u ^ 1;                      // LDS buffer / register stage of tile t+1 (t & 1 == u)
+        const float* an = As + nxt * SA::SIZE;
+        const float* bn = Bs + nxt * SB::SIZE;
+        // Q0
+        read_group(3, As + u * SA::SIZE, Bs + u * SB::SIZE);
+        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);       // tile t+2 into the stage tile t left
+        sb[u].load_fast(Bn + tl_delta, ldb, n0, k_begin + tl * BK, g.N);
+        {       // the tile after it (clamped to the last one; selects only: the iteration stays ONE basic block)
+          const bool adv = tl < last;
+          const bool wrap = tl_kin + BK >= seg_pad_k;
+          tl += adv ? 1 : 0;
+          tl_delta += (adv && wrap) ? seg_jump : 0;
+          tl_kin = adv ? (wrap ? 0 : tl_kin + BK) : tl_kin;
         }
+        mfma_group(0);
+        DPC_PIPE(0x100, N_DRG, 0x020, N_VM)
+        __builtin_amdgcn_sched_barrier(0);
+        // Q1
+        sa[nxt].store(As + nxt * SA::SIZE);         // tile t+1 (its loads were issued an iteration ago)
+        sb[nxt].store(Bs + nxt * SB::SIZE);
+        mfma_group(1);
+        DPC_PIPE(0, 0, 0x200, N_DW)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // Q2
+        read_group(0, an, bn);
+        read_group(1, an, bn);
+        mfma_group(2);
+        DPC_PIPE(0, 0, 0x100, 2 * N_DRG)
+        __builtin_amdgcn_sched_barrier(0);
+        // Q3
+        read_group(2, an, bn);
+        mfma_group(3);
+        DPC_PIPE(0, 0, 0x100, N_DRG)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+#undef DPC_PIPE
+    if (nfull & 1) {                                // the last full tile: groups 0-2 sit in the fragment registers already
+      read_group(3, As + ((nfull - 1) & 1) * SA::SIZE, Bs + ((nfull - 1) & 1) * SB::SIZE);
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) mfma_group(gi);
+    }
+    __syncthreads();                                // every wave is done with the LDS buffers (remainder / gather image next)
+    DPC_STAMP(2);                                   // K loop done
   }
   // Remainder (a partial last tile, or operands the fast path cannot take): one tile at a time.
   for (int t = nfull; t < ntile; ++t) {
@@ -356,6 +478,12 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     __syncthreads();
   }
 
+  if (CH == 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += acc2[i][j];
+  }
   if (gather) {
     static_assert(BM * BN <= 2 * SA::SIZE + 2 * SB::SIZE, "gather image must fit the operand buffers");
     if (GPRE && gvec) {
@@ -440,65 +568,94 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
           if (row < g.M) atomicAdd(g.C + (int64_t)row * g.ldc + ocol, g.alpha * av[e] + bv);
         }
       } else {
-        // Everything the epilogue READS per element (old C for beta, the multiplier, a stored keep mask, the
-        // BatchNorm block's y and z) is loaded for all 16 elements FIRST, from row-clamped addresses, under
-        // block-uniform conditions only: inside the per-element `row < M` branch every load was followed by a
-        // drained load queue - 16 to 48 dependent L2 round trips per MFMA tile.
+        // Straight-line phases over eight elements at a time, every choice between phases block-uniform and the ONLY
+        // per-lane guard the one around each store.  (The first form - one `if (row < M) { ... }` body per element
+        // holding loads, the activation switch and the store - came out of hipcc as sixteen blocks that each begin
+        // with s_waitcnt vmcnt(0): every element waited for the previous element's STORE to be acknowledged, 600-700
+        // cycles each.  The in-kernel stamps of tools/gemm_stamp.py showed an 11 000-cycle epilogue, 5 us of every
+        // product, for sixteen stores per lane.)
+        // What the epilogue READS per element (old C for beta, the multiplier, a stored keep mask, the BatchNorm
+        // block's y and z) is loaded first, from row- and column-clamped addresses.
         const float bmu = bnb ? g.bn_mean[col] : 0.f, bis = bnb ? g.bn_invstd[col] : 0.f;
         const bool ld_c = g.beta != 0.f, ld_aux = g.epi == EPI_MUL, ld_keep = g.epi == EPI_LEAKY_DROPOUT && g.keep != nullptr;
         const bool ld_bn = g.bn_y != nullptr;       // (block-uniform; lanes beyond stat_n read a clamped column and drop it)
         const int bcol = min(col, g.stat_n - 1);
+        const bool fwd_stat = g.colstat != nullptr && !ld_bn;
         // (eight elements at a time: all sixteen kept the kernel above 128 registers, three waves per SIMD instead of four)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-        float c_old[8], aux[8], by[8], bz[8];
-        uint8_t kp[8];
+          float c_old[8], aux[8], by[8], bz[8], v[8];
+          uint8_t kp[8];
+          bool ok[8];
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          const int e = 8 * h + e8;
-          const int64_t rowc = min(row0 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
-          c_old[e8] = ld_c ? g.C[rowc * g.ldc + ocol] : 0.f;
-          aux[e8] = ld_aux ? g.aux_in[rowc * g.ld_aux_in + col] : 1.f;
-          kp[e8] = ld_keep ? g.keep[rowc * g.ld_keep + col] : (uint8_t)0;
-          by[e8] = ld_bn ? g.bn_y[rowc * g.ld_bn_y + bcol] : 0.f;
-          bz[e8] = ld_bn ? g.bn_z[rowc * g.ld_bn_z + bcol] : 0.f;
-        }
+          for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = 8 * h + e8;
+            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+            ok[e8] = row < g.M;
+            const int64_t rowc = min(row, g.M - 1);
+            c_old[e8] = ld_c ? g.C[rowc * g.ldc + ocol] : 0.f;
+            aux[e8] = ld_aux ? g.aux_in[rowc * g.ld_aux_in + col] : 1.f;
+            kp[e8] = ld_keep ? g.keep[rowc * g.ld_keep + col] : (uint8_t)0;
+            by[e8] = ld_bn ? g.bn_y[rowc * g.ld_bn_y + bcol] : 0.f;
+            bz[e8] = ld_bn ? g.bn_z[rowc * g.ld_bn_z + bcol] : 0.f;
+            v[e8] = g.alpha * av[e] + bv;
+          }
+          if (gather) {
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          const int e = 8 * h + e8;
-          const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-          if (row < g.M) {
-            float v = g.alpha * av[e] + bv;
-            float* cp = g.C + (int64_t)row * g.ldc + ocol;
-            if (gather) v += lds[(row - m0) * BN + (col - n0)];
-            if (!g.bn_y) {
-              cs0 += v;
-              cs1 += v * v;
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int e = 8 * h + e8;
+              v[e8] += lds[(row0 - m0 + (e & 3) + 8 * (e >> 2) + 4 * lk) * BN + (col - n0)];
             }
-            if (g.epi == EPI_LEAKY_DROPOUT) {
-              float keep;
-              if (g.keep) {
-                keep = kp[e8] ? 1.f : 0.f;
-              } else {
-                keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
-              }
-              float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
-              g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
-              v *= slope;
-            } else if (g.epi == EPI_MUL) {
-              v *= aux[e8];
-            } else if (g.epi == EPI_RELU) {
-              v = fmaxf(v, 0.f);
+          }
+          if (fwd_stat) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const float m = ok[e8] ? v[e8] : 0.f;
+              cs0 += m;
+              cs1 += m * m;
             }
-            if (g.beta != 0.f) v += g.beta * c_old[e8];
-            *cp = v;
-            if (bnb) {
-              const float dyh = by[e8] > 0.f ? v : 0.f;
+          }
+          if (g.epi == EPI_LEAKY_DROPOUT) {
+            float slope[8];
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int e = 8 * h + e8;
+              const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+              const bool keep = g.keep ? (kp[e8] != 0) : ((dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) != 0);
+              slope[e8] = keep ? (v[e8] > 0.f ? 2.f : 2.f * g.leak) : 0.f;
+              v[e8] *= slope[e8];
+            }
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int e = 8 * h + e8;
+              const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+              if (ok[e8]) g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope[e8];
+            }
+          } else if (g.epi == EPI_MUL) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) v[e8] *= aux[e8];
+          } else if (g.epi == EPI_RELU) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) v[e8] = fmaxf(v[e8], 0.f);
+          }
+          if (ld_c) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) v[e8] += g.beta * c_old[e8];
+          }
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = 8 * h + e8;
+            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+            if (ok[e8]) g.C[(int64_t)row * g.ldc + ocol] = v[e8];
+          }
+          if (bnb) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const float dyh = (ok[e8] && by[e8] > 0.f) ? v[e8] : 0.f;
               cs0 += dyh;
               cs1 += dyh * ((bz[e8] - bmu) * bis);
             }
           }
-        }
         }
       }
     }
@@ -512,7 +669,9 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
       }
     }
   };
+  DPC_STAMP(7);                                     // accumulator chains summed, gather image staged
   tile_out(acc[0][0], m0 + wm0, n0 + wn0 + li);
+  DPC_STAMP(8);                                     // first MFMA tile's epilogue issued
   if constexpr (TN > 1) tile_out(acc[0][1], m0 + wm0, n0 + wn0 + 32 + li);
   if constexpr (TM > 1) {
     tile_out(acc[1][0], m0 + wm0 + 32, n0 + wn0 + li);
@@ -550,6 +709,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // (slot = split * tiles + tile): with 8 or more K chunks an XCD works on ONE chunk of K for all
   // tiles, so each XCD's L2 fetches its slice of A and B once - the whole product then reads A and B
   // about once from HBM instead of once per tile row / column and XCD.
+  DPC_STAMP(0);
+  DPC_STAMP_WALL(5);
   const int tiles = g.tiles_m * g.tiles_n;
   const int slot = gemm_xcd_slot(blockIdx.x, tiles * g.splitk);
   const int split = slot / tiles;
@@ -559,6 +720,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   int k_end = min(g.K, k_begin + g.kchunk);
   if (k_begin >= k_end && split > 0) return;
   gemm_segment<BM, BN, A_KC, B_KC, PF, KS>(g, lds, tile_m * BM, tile_n * BN, k_begin, k_end, g.splitk > 1 || g.force_atomic, split == 0);
+  DPC_STAMP(3);                                     // epilogue issued
+#ifdef DPC_GEMM_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  DPC_STAMP(4);                                     // ... and its stores acknowledged
+  DPC_STAMP_WALL(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -589,9 +756,9 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
   const int64_t ldb = B_KC ? g.b_cs : g.b_rs;
   const bool fa = g.a_vec && (A_KC ? true : (m0 + 32 <= g.M || (((g.M + 3) & ~3) <= lda && g.M >= 4)));
   const bool fb = g.b_vec && (B_KC ? true : (n0 + 32 <= g.N || (((g.N + 3) & ~3) <= ldb && g.N >= 4)));
-  f32x16 acc;
+  f32x16 acc, acc2;        // two accumulator chains per wave (even / odd k-steps): see gemm_segment
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
   SA sa[KS_GROUP];
   SB sb[KS_GROUP];
   const int ntile = (g.K + BK - 1) / BK;
@@ -619,12 +786,16 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
           SA::frag(As + j * TS, 0, kb, li, lk, a);
           SB::frag(Bs + j * TS, 0, kb, li, lk, b);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+          for (int q = 0; q < 4; q += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q + 1], b[q + 1], acc2, 0, 0, 0);
+          }
         }
       }
     }
   }
   // the four waves' partial tiles meet in LDS: red[wave][row][col], rows of 32 floats
+  acc += acc2;
   __syncthreads();
   float* red = lds;
 #pragma unroll

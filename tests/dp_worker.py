@@ -24,7 +24,8 @@ def shard(x, r, R, groups=False):
 def replay(dist, dev):
     from golden_util import Trace
     from dp_cgans_amd.engine import StepEngine
-    from test_engine_gpu import AdamAwareCompare, close, injected
+    from golden_util import AdamAwareCompare
+    from test_engine_gpu import close, injected
     tr = Trace('trace_np.npz')
     R, r = dist.world, dist.rank
     Bl = tr.B // R

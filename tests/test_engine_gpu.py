@@ -35,42 +35,7 @@ def close(a, b, rtol=RTOL, what='', scale=None):
     assert err <= rtol, '%s: max err / scale = %.3e' % (what, err)
 
 
-class AdamAwareCompare(object):
-    """Adam's update lr*m/(sqrt(v)+eps) is sign-like: for a gradient entry of rounding-noise size
-    (|g| within ~100 eps of zero, e.g. a unit that dropout silenced in every row) the update is
-    decided by summation order, on the reference's side too.  Entries whose reference gradient is
-    below 1e-5 of the tensor's largest are therefore held to |diff| <= lr per step taken so far, all
-    others to 1e-5 relative.  ``first_step_sensitivity`` (single-update checks of wide layers, where
-    thousands of entries sit near Adam's eps = 1e-8): at t = 1 the update is lr*g/(|g|+eps), so
-    d(update)/dg = lr*eps/(|g|+eps)^2; entries where a gradient error at the gradient's own bar (2e-5 of
-    the largest, checked separately and without any excuse) moves the update by more than half the
-    parameter bar are held to the looser bound as well."""
-
-    def __init__(self, lr=2e-4, first_step_sensitivity=False):
-        self.loose, self.steps, self.lr, self.sens = {}, 0, lr, first_step_sensitivity
-
-    def check(self, key, mine, ref_p, ref_g, what, mine_g=None):
-        # (exact zeros - e.g. cond columns no row of the batch selected - are NOT excused: both sides must leave them
-        # alone; with ``mine_g``, the one exception is a sum that cancels to exactly 0 in the reference's summation
-        # order and to rounding residue - below 1e-6 of the tensor's largest entry - in this one)
-        gmax, sc = max(np.abs(ref_g).max(), 1e-30), max(np.abs(ref_p).max(), 1e-30)
-        thr = 1e-5 * gmax
-        if self.sens:
-            assert self.steps == 1
-            thr = max(thr, np.sqrt(self.lr * 1e-8 * 2e-5 * gmax / (0.5 * RTOL * sc)))
-        tiny = (np.abs(ref_g) < thr) & (ref_g != 0)
-        if mine_g is not None:
-            mg = np.abs(mine_g.detach().cpu().numpy())
-            tiny |= (ref_g == 0) & (mg != 0) & (mg < 1e-6 * gmax)
-        self.loose[key] = tiny | self.loose.get(key, np.zeros_like(tiny))
-        lo = self.loose[key]
-        mine = mine.detach().cpu().numpy()
-        err = np.abs(mine - ref_p)
-        assert (err[~lo] / sc).max(initial=0.0) <= RTOL, '%s: %.3e' % (what, (err[~lo] / sc).max())
-        assert err[lo].max(initial=0.0) <= self.lr * self.steps, '%s (noise-sized grads): %.3e' % (what, err[lo].max())
-        # what the excuse covers is reported and capped: at most a tenth of a tensor's entries
-        self.worst = max(getattr(self, 'worst', 0.0), float(lo.mean()) if lo.size >= 64 else 0.0)
-        assert lo.size < 64 or lo.mean() <= 0.1, '%s: too many entries excused (%.3f)' % (what, lo.mean())
+from golden_util import AdamAwareCompare  # noqa: E402,F401  (shared with the CPU oracle tests and dp_worker.py)
 
 
 def make_engine(tr, device='cuda:0'):
@@ -104,13 +69,22 @@ def injected(tr, s, dev):
     return inj
 
 
-@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz', 'trace_num.npz'])
+# largest share of one tensor's entries AdamAwareCompare may hold to |diff| <= lr in the trace replays (what the runs
+# need + a margin; the shares themselves are in the test report: golden_util.AdamAwareCompare.report)
+EXCUSED_CEILING = {'trace_priv.npz': 0.07, 'trace_cfg2.npz': 0.03}       # seen: 0.056 (output layer, 56 x 678) and 0.0195 (5 of 256 biases)
+
+
+@pytest.mark.parametrize('name', ['trace_np.npz', 'trace_priv.npz', 'trace_num.npz', 'trace_cfg1.npz', 'trace_cfg2.npz'])
 def test_engine_replays_reference_training_steps(name):
     tr = Trace(name)
     eng = make_engine(tr)
     dev = eng.dev
     B, Dd, n = tr.B, eng.Dd, eng.n
-    cmp_d, cmp_g = AdamAwareCompare(), AdamAwareCompare()
+    # a trace that holds ONE update of a network (BASELINE configs 1 and 2's first iteration) checks that update with
+    # the first-step sensitivity bound: at t = 1 Adam's update is lr*g/(|g|+eps) and among the 10^5 entries of a
+    # full-size layer a few have |g| within rounding of eps (1.1e-5 seen against the 1e-5 bar)
+    cmp_d = AdamAwareCompare(first_step_sensitivity=tr.kinds.count('D') == 1, ceiling=EXCUSED_CEILING.get(name, 0.02))
+    cmp_g = AdamAwareCompare(first_step_sensitivity=tr.kinds.count('G') == 1, ceiling=EXCUSED_CEILING.get(name, 0.02))
     for s, kind in enumerate(tr.kinds):
         inj = injected(tr, s, dev)
         if kind == 'D':
@@ -161,8 +135,6 @@ def test_engine_replays_reference_training_steps(name):
                     assert np.abs(eng.gen.P(k).cpu().numpy() - ref_p[k]).max() < 2e-4 * cmp_g.steps
                 else:
                     cmp_g.check(k, eng.gen.P(k), ref_p[k], ref_g[k], 's%d G param %s' % (s, k))
-    print('%s: largest excused fraction of a tensor (noise-sized gradients): D %.4f, G %.4f'
-          % (name, getattr(cmp_d, 'worst', 0.0), getattr(cmp_g, 'worst', 0.0)))
     sd = eng.generator_state_dict()
     for k in tr.z.files:
         if k.startswith('gen_final/') and 'running' in k:
@@ -216,7 +188,7 @@ def test_step_against_oracle_on_odd_shapes(cfg):
     _check_step_against_oracle(enc, span, cfg['E'], cfg['g'], cfg['d'], cfg['B'], cfg['pac'])
 
 
-def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac, loop_loss=True, adam_sensitivity=False):
+def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac, loop_loss=True, adam_sensitivity=False, ceiling=0.03):
     from dp_cgans_amd import ops
     from dp_cgans_amd.data_sampler import DataSampler
     from dp_cgans_amd.engine import StepEngine
@@ -265,7 +237,7 @@ def _check_step_against_oracle(enc, span, E, gdim, ddim, B, pac, loop_loss=True,
         close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='D grad ' + k)
     mine_g = {k: eng.disc.G(k).clone() for k in eng.disc.keys}
     dp2 = onets.apply_update(dp, out['grads'], {'t': 0, 'm': {}, 'v': {}})
-    cmp_d = AdamAwareCompare(first_step_sensitivity=adam_sensitivity)
+    cmp_d = AdamAwareCompare(first_step_sensitivity=adam_sensitivity, ceiling=ceiling)      # (odd shapes: 0.023 seen)
     cmp_d.steps = 1
     for k in eng.disc.keys:
         cmp_d.check(k, eng.disc.P(k), dp2[k].numpy(), out['grads'][k].numpy(), 'D param ' + k, mine_g=mine_g[k])
@@ -510,7 +482,7 @@ def test_dpsgd_graph_replayed_training_steps_match_the_oracle_chain():
     sd, sg = {'t': 0, 'm': {}, 'v': {}}, {'t': 0, 'm': {}, 'v': {}}
     seed, seed_shared = int(eng.rng[0]), int(eng.rng_shared[0])
     gs = GraphStep(eng, d_steps=1)
-    cmp_d, cmp_g = AdamAwareCompare(), AdamAwareCompare()
+    cmp_d, cmp_g = AdamAwareCompare(ceiling=0.02), AdamAwareCompare(ceiling=0.04)      # (0.028 seen on the 56 x 104 output layer)
 
     def draws(step, k, rows):
         rng = torch.tensor([seed, step], dtype=torch.int64, device=dev)

@@ -229,6 +229,8 @@ def install_patches():
         for i, p in enumerate(ps):
             REC.add('p_after_%d' % i, t2n(p))
         STEP_SINK.append(REC.pop_all())
+        if LIMIT['n'] and len(STEP_SINK) >= LIMIT['n']:
+            raise StopCapture()           # the trace holds what it was asked for: leave fit() here
         return out
 
     torch.optim.Adam.step = step
@@ -258,6 +260,11 @@ def install_patches():
 STEP_SINK = []
 SEEN_OPT = set()
 FIT_ARGS = {}
+LIMIT = {'n': 0}      # stop a fit after this many optimiser steps (0: run it to the end)
+
+
+class StopCapture(Exception):
+    pass
 
 
 def flatten(prefix, bucket, out):
@@ -275,7 +282,11 @@ def gm_params(gm):
         precisions_cholesky=gm.precisions_cholesky_.reshape(-1))
 
 
-def run_trace(private, out_path, csv, numeric_only=False):
+def run_trace(private, out_path, csv, numeric_only=False, batch_size=100, gen_dim=(48, 32), disc_dim=(32, 24),
+              embedding_dim=16, d_steps=2, pac=10, max_opt_steps=0):
+    """``max_opt_steps``: leave fit() after that many optimiser steps (the first iteration of BASELINE configs 1 and 2:
+    their full-size parameter tensors make every recorded step a megabyte or more; config 2's epoch end would
+    also raise in the reference's accountant at q = batch / rows = 2.5)."""
     import pandas as pd
     import torch
     from dp_cgans import DP_CGAN
@@ -287,10 +298,16 @@ def run_trace(private, out_path, csv, numeric_only=False):
     df = pd.read_csv(csv)
     if numeric_only:          # a table without discrete columns (no cond vector, raw output to D)
         df = df.select_dtypes('number')
-    model = DP_CGAN(epochs=1, batch_size=100, generator_dim=(48, 32), discriminator_dim=(32, 24),
-                    embedding_dim=16, discriminator_steps=2, pac=10, private=private, cuda=False,
+    model = DP_CGAN(epochs=1, batch_size=batch_size, generator_dim=tuple(gen_dim), discriminator_dim=tuple(disc_dim),
+                    embedding_dim=embedding_dim, discriminator_steps=d_steps, pac=pac, private=private, cuda=False,
                     verbose=False)
-    model.fit(df)
+    LIMIT['n'] = max_opt_steps
+    try:
+        model.fit(df)
+    except StopCapture:
+        pass
+    finally:
+        LIMIT['n'] = 0
     synth = FIT_ARGS['self']
     out = {}
     # Everything drawn before the first optimiser step that belongs to fit/transform is in step 0's
@@ -310,9 +327,9 @@ def run_trace(private, out_path, csv, numeric_only=False):
         for sp in col:
             info.append((sp.dim, 0 if sp.activation_fn == 'tanh' else 1, len(col)))
     out['span_info'] = np.array(info, dtype=np.int32)   # (dim, is_softmax, spans_in_column)
-    out['config'] = np.array([100, 16, 10, 2, int(private)], dtype=np.int32)  # B,E,pac,d_steps,private
-    out['gen_dim'] = np.array([48, 32], np.int32)
-    out['disc_dim'] = np.array([32, 24], np.int32)
+    out['config'] = np.array([batch_size, embedding_dim, pac, d_steps, int(private)], dtype=np.int32)  # B,E,pac,d_steps,private
+    out['gen_dim'] = np.array(list(gen_dim), np.int32)
+    out['disc_dim'] = np.array(list(disc_dim), np.int32)
     np.savez_compressed(out_path, **out)
     return synth
 
@@ -444,9 +461,24 @@ def capture_rdp(outdir):
                         orders=np.array(orders))
 
 
+def capture_config_traces(out, csv, tmp):
+    """The first iteration of the reference's loop at the hyper-parameters BASELINE.json names for configs 1 and 2:
+    config 1 - batch 100, embedding 128, G/D dims (128,128,128), discriminator_steps 5 (tests/test_dp_cgans.py:17-28),
+    private=False: 5 D updates + 1 G update; config 2 - batch 500, pac 10, default dims (256,256), private=True (the
+    reference's hook noise + clamp): 1 D update + 1 G update."""
+    run_trace(False, os.path.join(out, 'trace_cfg1.npz'), csv, batch_size=100, gen_dim=(128, 128, 128),
+              disc_dim=(128, 128, 128), embedding_dim=128, d_steps=5, pac=10, max_opt_steps=6)
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    run_trace(True, os.path.join(out, 'trace_cfg2.npz'), csv, batch_size=500, gen_dim=(256, 256),
+              disc_dim=(256, 256), embedding_dim=128, d_steps=1, pac=10, max_opt_steps=2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default=None, choices=['configs'],
+                    help="'configs': only the traces at BASELINE configs 1 and 2's own hyper-parameters (round 3)")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
@@ -457,6 +489,9 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)            # the reference writes fitted_transformer.pkl / loss_output_*.txt to cwd
         try:
+            if args.only == 'configs':
+                capture_config_traces(out, csv, tmp)
+                return
             capture_rdp(out)
             capture_encode_and_sampler(out, csv)
             for f in os.listdir(tmp):
