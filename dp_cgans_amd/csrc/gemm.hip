@@ -104,7 +104,15 @@ __device__ unsigned long long* dpc_stamp_buf = nullptr;
 extern "C" int dpc_debug_stamp_buffer(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(dpc_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -2;
 }
+// DPC_EXP=<bits>: leave a class of instructions OUT of the K loop (results wrong; timing only): 1 global loads,
+// 2 LDS stores, 4 fragment reads, 8 the barrier
+#ifdef DPC_EXP
+#define DPC_EXP_IF(k) if (!((DPC_EXP >> ((k) - 1)) & 1))
 #else
+#define DPC_EXP_IF(k)
+#endif
+#else
+#define DPC_EXP_IF(k)
 #define DPC_STAMP(i) do {} while (0)
 #define DPC_STAMP_WALL(i) do {} while (0)
 #endif
@@ -144,6 +152,37 @@ struct Stage {
         r[p] = *reinterpret_cast<const f32x4u*>(base + (int64_t)(k0 + p * RPP + t / TPR) * ld + mn);
         if (KS) sc[p] = ks[k0 + p * RPP + t / TPR];
       }
+    }
+  }
+
+  // The K loop's form of load_fast: the per-thread part of every address is loop-invariant - `off` (elements, fits 32
+  // bits: checked on the host) from offsets() below - and only the block-uniform tile base moves from tile to tile,
+  // so each load is one instruction with a scalar base and a 32-bit vector offset and the loop carries no 64-bit
+  // vector address arithmetic (sixteen v_lshl_add_u64 per K-tile before: ~240 of a lone wave's 1450 cycles).
+  //   tile_base: base + k0 (k-contiguous operand) or base + k0 * ld (m/n-contiguous);  ks_tile: ks + k0
+  __device__ __forceinline__ void offsets(int64_t ld, int mn0, int MN, uint32_t off[PASSES], uint32_t koff[PASSES]) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      if (KC) {
+        const int row = min(mn0 + p * 32 + (t >> 3), MN - 1);
+        off[p] = (uint32_t)((int64_t)row * ld + 4 * (t & 7));
+        koff[p] = 0;
+      } else {
+        constexpr int TPR = BMN / 4;
+        constexpr int RPP = 256 / TPR;
+        const int mn = min(mn0 + 4 * (t % TPR), ((MN + 3) & ~3) - 4);
+        off[p] = (uint32_t)((int64_t)(p * RPP + t / TPR) * ld + mn);
+        koff[p] = (uint32_t)(p * RPP + t / TPR);
+      }
+    }
+  }
+  __device__ __forceinline__ void load_tile(const float* __restrict__ tile_base, const uint32_t off[PASSES],
+                                            const float* __restrict__ ks_tile, const uint32_t koff[PASSES]) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      r[p] = *reinterpret_cast<const f32x4u*>(tile_base + off[p]);
+      if (KS) sc[p] = ks_tile[koff[p]];
     }
   }
 
@@ -241,12 +280,12 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
   const int li = lane & 31, lk = lane >> 5;
 
-  // Accumulator chains.  Back-to-back v_mfma_f32_32x32x2_f32 on ONE accumulator issue every ~96 cycles, not 64 (SQ
-  // counters of a lone 64x64 block: MFMA-busy exactly 64 cycles per instruction, but 1546 wave-cycles per 16-MFMA
-  // K-tile, 70 % of them SQ_WAIT_INST_ANY - the dependent-accumulator latency).  A wave that owns a single 32x32
-  // tile therefore keeps TWO chains (even and odd k-steps) and adds them before the epilogue; with 2 x 2 tiles
-  // per wave the four tiles' chains interleave already.
-  constexpr int CH = (TM * TN == 1) ? 2 : 1;
+  // Accumulator chains: ONE per 32x32 tile.  (A second chain for the even / odd k-steps of a wave that owns a single
+  // tile was measured - in-kernel stamps, lone block and full grids - and changed nothing: 1661 against 1656 cycles
+  // per K-tile.  The SQ counters show MFMA-busy at exactly 64 cycles per instruction but ~97 wave-cycles between two
+  // MFMAs of a lone wave whatever their dependence; what closes the gap is more waves per SIMD - 84 % of the MFMA rate
+  // at two, 98 % at three - so registers are better spent on occupancy than on a second chain.)
+  constexpr int CH = 1;
   f32x16 acc[TM][TN], acc2[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -392,8 +431,20 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
     const bool seg_k = B_KC && g.seg_b == 1;
     const int seg_pad_k = seg_k ? g.seg_pad : 0x40000000;
     const int64_t seg_jump = seg_k ? g.seg_stride - g.seg_pad : 0;
-    int64_t tl_delta = seg_k ? gemm_seg_delta(g, k_begin + tl * BK) : 0;
     int tl_kin = seg_k ? (k_begin + tl * BK) % g.seg_pad : 0;
+    // block-uniform tile bases (scalar registers) + loop-invariant per-thread offsets: see Stage::load_tile
+    const int64_t a_step = A_KC ? BK : (int64_t)BK * lda, b_step = B_KC ? BK : (int64_t)BK * ldb;
+    const float* a_tile = g.A + (int64_t)(k_begin + tl * BK) * (A_KC ? 1 : lda);
+    const float* b_tile = g.B + (seg_k ? gemm_seg_delta(g, k_begin + tl * BK) : 0) + (int64_t)(k_begin + tl * BK) * (B_KC ? 1 : ldb);
+    const float* ks_tile = KS ? g.kscale + k_begin + tl * BK : nullptr;
+    uint32_t a_off[SA::PASSES], a_koff[SA::PASSES], b_off[SB::PASSES], b_koff[SB::PASSES];
+    sa[0].offsets(lda, m0, g.M, a_off, a_koff);
+    sb[0].offsets(ldb, n0, g.N, b_off, b_koff);
+    if (!B_KC && g.seg_b == 2) {        // an N segment map shifts each thread's columns: part of its invariant offset
+      const uint32_t dn = (uint32_t)(Bn - g.B);
+#pragma unroll
+      for (int p = 0; p < SB::PASSES; ++p) b_off[p] += dn;
+    }
     // Issue order inside an iteration.  One wave per SIMD hides NOTHING behind its own MFMAs unless the other
     // instructions sit BETWEEN them: hipcc's own schedule put the sixteen MFMAs of a K-tile back to back and the
     // loads, LDS stores and fragment reads in clusters between the groups, and the SQ counters of a lone block
@@ -424,35 +475,44 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
         const float* an = As + nxt * SA::SIZE;
         const float* bn = Bs + nxt * SB::SIZE;
         // Q0
-        read_group(3, As + u * SA::SIZE, Bs + u * SB::SIZE);
-        sa[u].load_fast(g.A, lda, m0, k_begin + tl * BK, g.M, g.kscale);       // tile t+2 into the stage tile t left
-        sb[u].load_fast(Bn + tl_delta, ldb, n0, k_begin + tl * BK, g.N);
+        DPC_EXP_IF(3) read_group(3, As + u * SA::SIZE, Bs + u * SB::SIZE);
+        DPC_EXP_IF(1) {
+        sa[u].load_tile(a_tile, a_off, ks_tile, a_koff);       // tile t+2 into the stage tile t left
+        sb[u].load_tile(b_tile, b_off, nullptr, b_koff);
+        }
+        DPC_EXP_IF(5)
         {       // the tile after it (clamped to the last one; selects only: the iteration stays ONE basic block)
           const bool adv = tl < last;
           const bool wrap = tl_kin + BK >= seg_pad_k;
           tl += adv ? 1 : 0;
-          tl_delta += (adv && wrap) ? seg_jump : 0;
+          a_tile += adv ? a_step : 0;
+          b_tile += adv ? (wrap ? b_step + seg_jump : b_step) : 0;
+          if (KS) ks_tile += adv ? BK : 0;
           tl_kin = adv ? (wrap ? 0 : tl_kin + BK) : tl_kin;
         }
         mfma_group(0);
         DPC_PIPE(0x100, N_DRG, 0x020, N_VM)
         __builtin_amdgcn_sched_barrier(0);
         // Q1
+        DPC_EXP_IF(2) {
         sa[nxt].store(As + nxt * SA::SIZE);         // tile t+1 (its loads were issued an iteration ago)
         sb[nxt].store(Bs + nxt * SB::SIZE);
+        }
         mfma_group(1);
         DPC_PIPE(0, 0, 0x200, N_DW)
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        DPC_EXP_IF(4) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         // Q2
+        DPC_EXP_IF(3) {
         read_group(0, an, bn);
         read_group(1, an, bn);
+        }
         mfma_group(2);
         DPC_PIPE(0, 0, 0x100, 2 * N_DRG)
         __builtin_amdgcn_sched_barrier(0);
         // Q3
-        read_group(2, an, bn);
+        DPC_EXP_IF(3) read_group(2, an, bn);
         mfma_group(3);
         DPC_PIPE(0, 0, 0x100, N_DRG)
         __builtin_amdgcn_sched_barrier(0);
@@ -584,22 +644,39 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
         // (eight elements at a time: all sixteen kept the kernel above 128 registers, three waves per SIMD instead of four)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          float c_old[8], aux[8], by[8], bz[8], v[8];
+          float c_old[8], aux[8], by[8], bz[8], v[8];      // (each read only under the condition it was loaded under)
           uint8_t kp[8];
           bool ok[8];
+          const int rbase = row0 + 16 * h + 4 * lk;        // element e8 of this half: row rbase + (e8 & 3) + 8 * (e8 >> 2)
+          const int mlast = g.M - 1;
 #pragma unroll
-          for (int e8 = 0; e8 < 8; ++e8) {
-            const int e = 8 * h + e8;
-            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-            ok[e8] = row < g.M;
-            const int64_t rowc = min(row, g.M - 1);
-            c_old[e8] = ld_c ? g.C[rowc * g.ldc + ocol] : 0.f;
-            aux[e8] = ld_aux ? g.aux_in[rowc * g.ld_aux_in + col] : 1.f;
-            kp[e8] = ld_keep ? g.keep[rowc * g.ld_keep + col] : (uint8_t)0;
-            by[e8] = ld_bn ? g.bn_y[rowc * g.ld_bn_y + bcol] : 0.f;
-            bz[e8] = ld_bn ? g.bn_z[rowc * g.ld_bn_z + bcol] : 0.f;
-            v[e8] = g.alpha * av[e] + bv;
+          for (int e8 = 0; e8 < 8; ++e8) ok[e8] = rbase + (e8 & 3) + 8 * (e8 >> 2) < g.M;
+          // ONE block-uniform branch per kind of input (a `cond ? load : 0` per element became a branch per element:
+          // forty taken branches through cold code per half - the instruction fetch of a block's once-only epilogue
+          // was most of its 5 000 cycles)
+          if (ld_c) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) c_old[e8] = g.C[(int64_t)min(rbase + (e8 & 3) + 8 * (e8 >> 2), mlast) * g.ldc + ocol];
           }
+          if (ld_aux) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) aux[e8] = g.aux_in[(int64_t)min(rbase + (e8 & 3) + 8 * (e8 >> 2), mlast) * g.ld_aux_in + col];
+          }
+          if (ld_keep) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) kp[e8] = g.keep[(int64_t)min(rbase + (e8 & 3) + 8 * (e8 >> 2), mlast) * g.ld_keep + col];
+          }
+          if (ld_bn) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int64_t rc = min(rbase + (e8 & 3) + 8 * (e8 >> 2), mlast);
+              by[e8] = g.bn_y[rc * g.ld_bn_y + bcol];
+              bz[e8] = g.bn_z[rc * g.ld_bn_z + bcol];
+            }
+          }
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) v[e8] = g.alpha * av[8 * h + e8] + bv;
+          if (h == 0) DPC_STAMP(9);
           if (gather) {
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
@@ -642,12 +719,14 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) v[e8] += g.beta * c_old[e8];
           }
+          if (h == 0) DPC_STAMP(10);
 #pragma unroll
           for (int e8 = 0; e8 < 8; ++e8) {
             const int e = 8 * h + e8;
             const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
             if (ok[e8]) g.C[(int64_t)row * g.ldc + ocol] = v[e8];
           }
+          if (h == 0) DPC_STAMP(11);
           if (bnb) {
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
@@ -703,7 +782,7 @@ __device__ __forceinline__ int gemm_xcd_slot(int bid, int n) {
 
 // Data-parallel kernel: one block per tile (gridDim.y > 1: per K chunk of a split-K product).
 template <int BM, int BN, bool A_KC, bool B_KC, int PF, bool KS = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BM == 128 ? 2 : 3)) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2 * Stage<BM, A_KC, KS>::SIZE + 2 * Stage<BN, B_KC>::SIZE];
   // 1-D grid of tiles x splitk blocks.  An XCD's contiguous run of slots is taken in split-major order
   // (slot = split * tiles + tile): with 8 or more K chunks an XCD works on ONE chunk of K for all

@@ -339,11 +339,29 @@ static int noalloc_scratch(double** out) {
 // dpc_colreduce_finish(kind 1) - bit-identical results.  Allocates nothing; F <= 8192.  Every call on
 // a GPU uses that GPU's one scratch array (all R x F partials it reads are rewritten first, nothing
 // needs clearing): calls that overlap on one GPU - two streams, two threads - race.
+// The FIRST call on a device looks the array's address up (hipGetSymbolAddress, under a mutex): make it outside any
+// stream capture - a warm-up call at set-up - and every later call on that device is launches only.
 extern "C" int dpc_colsum_noalloc(const float* x, int64_t ldx, int64_t rows, int F, const float* w, float* out,
                                   int accumulate, void* stream) {
   DPC_CHECK_ARG(x && out, "colsum_noalloc: null pointer");
   DPC_CHECK_ARG(rows > 0 && F > 0 && ldx >= F, "colsum_noalloc: bad shape");
   DPC_CHECK_ARG(F <= DPC_NOALLOC_MAX_F, "colsum_noalloc: more than 8192 columns (the static scratch holds 64 x 8192 partial sums)");
+  // The scratch array used is the CURRENT device's copy, and the kernels run on `stream`: all of x, out (and w) must
+  // live on the current device, or the launch would hand one GPU's scratch address to another GPU's kernel.
+  {
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) { dpc_set_error(hipGetErrorString(e)); return DPC_EHIP; }
+    const void* ptrs[3] = {x, out, w};
+    for (int i = 0; i < 3; ++i) {
+      if (!ptrs[i]) continue;
+      hipPointerAttribute_t at;
+      e = hipPointerGetAttributes(&at, ptrs[i]);
+      if (e != hipSuccess) { (void)hipGetLastError(); dpc_set_error("colsum_noalloc: x, out and w must be device pointers"); return DPC_EINVAL; }
+      DPC_CHECK_ARG(at.type == hipMemoryTypeDevice && at.device == cur,
+                    "colsum_noalloc: x, out and w must live on the current device (its scratch array is the one used)");
+    }
+  }
   double* part = nullptr;
   int rc = noalloc_scratch(&part);
   if (rc != DPC_OK) return rc;

@@ -465,6 +465,21 @@ extern "C" int dpc_adam_step_slices(float* p, float* g, float* m, float* v, int6
     sl.off = s_off[k]; sl.rows = s_rows[k]; sl.ld = s_ld[k]; sl.col0 = s_col0[k]; sl.ncol = s_ncol[k]; sl.gT = s_gT[k];
     sl.ld_gT = s_ld_gT[k]; sl.pT = s_pT[k]; sl.ld_pT = s_ld_pT[k];
   }
+  // ... and the converse: the flat blocks skip EVERY cond column of a listed matrix, so the slices must cover them
+  // all, exactly once - a column left out would never be updated (p, m and v would silently go stale)
+  for (int q = 0; q < nmat; ++q) {
+    const int64_t per_row = (int64_t)(m_ld[q] / m_period[q]) * (m_period[q] - m_col0[q]) +
+                            (m_ld[q] % m_period[q] > m_col0[q] ? m_ld[q] % m_period[q] - m_col0[q] : 0);
+    int64_t covered = 0;
+    for (int k = 0; k < nslice; ++k) {
+      if (s_off[k] != m_off[q] || s_ld[k] != m_ld[q]) continue;
+      covered += s_ncol[k];
+      for (int j = 0; j < k; ++j)
+        DPC_CHECK_ARG(s_off[j] != s_off[k] || s_col0[j] + s_ncol[j] <= s_col0[k] || s_col0[k] + s_ncol[k] <= s_col0[j],
+                      "adam_slices: two slices of one matrix overlap");
+    }
+    DPC_CHECK_ARG(covered == per_row, "adam_slices: the slices of a matrix must cover all of its cond columns (the flat pass skips them)");
+  }
   a.nmat = nmat; a.nslice = nslice;
   return adam_launch(a, stream);
 }

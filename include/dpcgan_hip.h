@@ -317,7 +317,10 @@ int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int
  * partial sums live in a 4 MiB file-scope device array of the library (one copy per GPU, held until the
  * process ends).  No counterpart in the reference; it is for callers that cannot allocate (HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  Bit-identical to that pair of calls.
- * F <= 8192 (DPC_EINVAL beyond).  Calls that overlap on one GPU share the array and race. */
+ * F <= 8192 (DPC_EINVAL beyond).  Calls that overlap on one GPU share the array and race.
+ * x, out and w must live on the CURRENT device (DPC_EINVAL otherwise: the current device's copy of the array is the
+ * one used).  The first call on a device looks the array's address up (not a capturable call): make one warm-up
+ * call per device outside stream capture; later calls there are two launches and nothing else. */
 int dpc_colsum_noalloc(const float* x, int64_t ldx, int64_t rows, int F, const float* w, float* out,
                        int accumulate, void* stream);
 int dpc_bn_relu_fwd(const float* z, int64_t ldz, float* y, int64_t ldy, int64_t B, int F,

@@ -416,6 +416,15 @@ def test_adam_with_cond_slices_equals_transposes_around_the_plain_step(ops, nois
     mats = [(view(p4, 1), 45, 30), (view(p4, 3), 26, 17)]
     ops.adam_step_slices(p4, g4, m4, v4, 2e-4, 1e-6, mats, [(view(p4, k), c0, nc, None, None) for k, c0, nc in sl], **kw)
     assert torch.equal(p3, p4) and torch.equal(m3, m4) and torch.equal(v3, v4) and torch.equal(g4, g0)
+    # the flat pass skips every cond column of a listed matrix: a call whose slices leave one of them out (it would
+    # never be updated), or name a column twice, is refused and touches nothing
+    p5, g5, m5, v5 = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    mats = [(view(p5, 1), 45, 30), (view(p5, 3), 26, 17)]
+    for bad in (sl[:2], [sl[0], sl[1], (3, 43, 8)], sl + [(3, 43, 9)], [sl[0], sl[1], (3, 42, 10)]):
+        with pytest.raises(RuntimeError, match='adam_slices'):
+            ops.adam_step_slices(p5, g5, m5, v5, 2e-4, 1e-6, mats, [(view(p5, k), c0, nc, None, None) for k, c0, nc in bad], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(p5, p0) and torch.equal(m5, m0) and torch.equal(v5, v0)
 
 
 # ------------------------------------------------------------------------------------------------

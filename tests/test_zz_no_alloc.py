@@ -51,3 +51,25 @@ def test_colsum_noalloc_rejects_more_columns_than_its_scratch_holds():
     out = torch.zeros(8192, device=DEV)
     ops.colsum_noalloc(ok, out)
     assert torch.equal(out, torch.full((8192,), 4.0, device=DEV))
+
+
+def test_colsum_noalloc_rejects_operands_that_are_not_on_the_current_device():
+    """Through the bare C-ABI (the ops wrapper has its own device check): a host pointer, and - where a second GPU
+    is visible - operands of another device than the current one."""
+    import ctypes
+    from dp_cgans_amd._lib import lib
+    L = lib()
+    x = torch.ones(8, 16, device=DEV)
+    out = torch.zeros(16, device=DEV)
+    host = torch.ones(8, 16)
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    with pytest.raises(RuntimeError, match='colsum_noalloc'):
+        L.call('dpc_colsum_noalloc', host.data_ptr(), 16, 8, 16, None, out.data_ptr(), 0, st)
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1):
+            with pytest.raises(RuntimeError, match='current device'):
+                L.call('dpc_colsum_noalloc', x.data_ptr(), 16, 8, 16, None, out.data_ptr(), 0,
+                       torch.cuda.current_stream(1).cuda_stream)
+    L.call('dpc_colsum_noalloc', x.data_ptr(), 16, 8, 16, None, out.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.full((16,), 8.0, device=DEV))

@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dp_cgans_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'tools', '_stamp', 'libdpcgan_stamp.so')
+_lib.LIB_PATH = os.environ.get('DPC_STAMP_LIB') or os.path.join(ROOT, 'tools', '_stamp', 'libdpcgan_stamp.so')
 import numpy as np
 import torch
 from dp_cgans_amd import ops
@@ -56,8 +56,10 @@ def run(tag, M, N, K, ta=False, tb=True, reps=30, **kw):
           '(%5.2f us) = prologue %5.0f + loop %6.0f (%5.0f per K-tile) + epilogue %5.0f + store-ack %5.0f | clock %.2f GHz'
           % (tag, M, N, K, nblk, us, span / 1e3, med(tot), med(wall) / 1e3, med(pro), med(loop), med(loop) / ktiles,
              med(epi), med(ack), ghz))
-    print('%-18s   epilogue split: loop end -> tile_out %5.0f, first tile_out %5.0f, rest %5.0f cycles'
-          % ('', med(s[:, 7] - s[:, 2]), med(s[:, 8] - s[:, 7]), med(s[:, 3] - s[:, 8])))
+    print('%-18s   epilogue split: loop end -> tile_out %5.0f, first tile_out %5.0f (entry -> loads + values %5.0f, -> '
+          'activation %5.0f, -> 8 stores %5.0f, second half %5.0f), rest %5.0f cycles'
+          % ('', med(s[:, 7] - s[:, 2]), med(s[:, 8] - s[:, 7]), med(s[:, 9] - s[:, 7]), med(s[:, 10] - s[:, 9]),
+             med(s[:, 11] - s[:, 10]), med(s[:, 8] - s[:, 11]), med(s[:, 3] - s[:, 8])))
     # start-time spread of the blocks (dispatch ramp) and the last block's finish
     start = (s[:, 5] - s[:, 5].min()) * 10.0
     print('%-18s   block starts: median +%.2f us, 90 %% +%.2f us, last +%.2f us' % ('', np.median(start) / 1e3,
@@ -65,6 +67,11 @@ def run(tag, M, N, K, ta=False, tb=True, reps=30, **kw):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'loop':         # the K loop only (instruction-class experiments: DPC_EXP builds)
+        print(os.path.basename(_lib.LIB_PATH))
+        run('lone block', 64, 64, 2048, tile=64, splitk=1)
+        run('2 blocks/CU', 8192, 256, 2048, tile=64, splitk=1)
+        sys.exit(0)
     run('lone block', 64, 64, 256, tile=64, splitk=1)
     run('lone block', 64, 64, 2048, tile=64, splitk=1)
     run('1 block/CU', 4096, 256, 512, tile=64, splitk=1)
