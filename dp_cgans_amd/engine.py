@@ -205,6 +205,7 @@ class StepEngine(object):
             weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
+        self._ar_fault = None
         self._early_hook = None
         self.early_at = os.environ.get('DPCGAN_EARLY_AT', 'd_forward')     # where train_step forks the generator update's forward
         self._inline = False
@@ -927,6 +928,9 @@ class StepEngine(object):
     def _allreduce(self, t):
         if not self.dist.active:
             return t
+        if self._ar_fault is not None:     # test hook (GraphStep.INJECT_CAPTURE_FAULT): the next collective raises once
+            fault, self._ar_fault = self._ar_fault, None
+            raise fault
         if self._ar_hook is not None:      # graph capture in progress, the collective runs between graph segments:
             self._join()                   # a graph cut needs every branch back on the main stream
             self._join_early()
@@ -1383,6 +1387,8 @@ class GraphStep(object):
     step into graph segments, ``[graph, all-reduce, graph, ...]``.
     """
 
+    INJECT_CAPTURE_FAULT = False     # test hook: the first collective of the in-graph capture raises (exercises the fallback)
+
     def __init__(self, eng, d_steps=1):
         self.eng, self.d_steps = eng, int(d_steps)
         self.items = None
@@ -1399,6 +1405,8 @@ class GraphStep(object):
         eng = self.eng
         in_graph = getattr(eng.dist, 'backend', None) == 'nccl' and os.environ.get('DPCGAN_GRAPH_COLLECTIVES') != '0'
         if in_graph:
+            if GraphStep.INJECT_CAPTURE_FAULT:
+                eng._ar_fault = RuntimeError('injected: collective refused on a capturing stream')
             try:
                 self._capture(True)
                 return
@@ -1431,11 +1439,20 @@ class GraphStep(object):
             try:
                 self._body()
             except Exception:
-                try:                            # leave capture mode before the error travels on
+                # Leave capture mode before the error travels on.  The step was cut short with branches open (side
+                # streams, the early lane): they are joined back into the capturing stream first, so that the capture
+                # ENDS CLEANLY - an end with unjoined work invalidates it and can leave those streams unusable for the
+                # second capture - and the partial graph is dropped.
+                try:
+                    eng._inline = False
+                    eng._join()
+                    eng._join_early()
+                    for st in list(eng.side) + ([eng.early] if eng.early is not None else []):
+                        torch.cuda.current_stream(eng.dev).wait_stream(st)
                     state['g'].capture_end()
                 except Exception:               # noqa: BLE001
                     pass
-                eng._open, eng._early_open, eng._early_hook = [], False, None
+                eng._open, eng._early_open, eng._early_hook, eng._ar_fault = [], False, None, None
                 eng.bn_batches = batches
                 raise
             finally:

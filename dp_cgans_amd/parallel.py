@@ -22,7 +22,9 @@ class Dist(object):
         # (process group, all-reduce on the device, graph segments cut at the collectives) is
         # exercised on a one-GPU box
         self.active = self.world > 1 or os.environ.get('DPCGAN_FORCE_DIST') == '1'
+        self.owns_group = False       # True when THIS object created the process group (then shutdown() destroys it)
         if self.active and not dist.is_initialized():
+            self.owns_group = True
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
@@ -67,5 +69,9 @@ class Dist(object):
         return int(t.item())
 
     def shutdown(self):
-        if self.active and dist.is_initialized():
+        """Destroy the process group if this object created it (a group the caller set up stays the caller's); the
+        object then behaves as a single rank: no collectives."""
+        if self.active and self.owns_group and dist.is_initialized():
             dist.destroy_process_group()
+            self.owns_group = False
+            self.active = False

@@ -196,10 +196,16 @@ class DPCGANSynthesizer(object):
                 DeprecationWarning)
         # every launch below goes to the current stream of self._device: make it the current device
         with torch.cuda.device(self._device):
-            self._fit(train_data, discrete_columns, epochs)
+            dist = Dist(device=self._device)    # first: it decides which rank writes files and whose entropy keys the fit
+            try:
+                self._fit(train_data, discrete_columns, epochs, dist)
+                dist.barrier()
+            finally:
+                # a process group this fit created ends with it (one the caller initialised is left alone); the
+                # engine then runs as a single rank: sample() draws and normalises per rank
+                dist.shutdown()
 
-    def _fit(self, train_data, discrete_columns, epochs):
-        dist = Dist(device=self._device)        # first: it decides which rank writes files and whose entropy keys the fit
+    def _fit(self, train_data, discrete_columns, epochs, dist):
         base_seed = self._base_seed(dist)
         # the transformer is pickled with the model: its stream key is a one-way digest of the fit's key,
         # so a saved model never reveals the key of the DP noise stream

@@ -83,6 +83,58 @@ def replay(dist, dev):
                 close(sd[k[len('gen_final/'):]], tr.z[k], scale=sc, what=k)
 
 
+def replay_dpsgd(dist, dev, clip_quantile):
+    """DP-SGD sharding proof: every rank runs its row shard of the reference trace's first discriminator update in
+    dp_mode='dpsgd' (per-rank per-example norms and clip factors, clipped sums all-reduced, ONE noise tensor added by
+    every rank after the all-reduce) and compares with oracle/dpsgd.py run single-process on the GLOBAL batch:
+    norms and clip factors of its own examples, the clipped mean gradient, the noised + Adam-updated parameters."""
+    from golden_util import Trace
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import dpsgd
+    from oracle import nets as onets
+    from test_engine_gpu import _flat_noise, close, injected
+    tr = Trace('trace_np.npz')
+    R, r = dist.world, dist.rank
+    s = tr.kinds.index('D')
+    dp = {k: torch.from_numpy(v) for k, v in tr.params(s, 'p_before').items()}
+    gp = {k: torch.from_numpy(v) for k, v in tr.params(tr.kinds.index('G'), 'p_before').items()}
+    full = injected(tr, s, dev)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [m.cpu() for m in v]) for k, v in full.items()}
+    n = tr.B // tr.pac
+    mk = lambda g: [m[g * n:(g + 1) * n] for m in cpu['keep']]
+    args = (gp, dp, tr.span_info, tr.pac, cpu['z'], cpu['cond'], cpu['perm'], cpu['real'], cpu['exp'], mk(0), mk(1), mk(2),
+            cpu['alpha'])
+    norms = dpsgd.d_step_grads_dpsgd(*args, clip=1e30)['norms'].numpy()
+    clip = {'none': float(norms.max()) * 2, 'median': float(np.median(norms)), 'all': float(norms.min()) * 0.5}[clip_quantile]
+    sigma = 0.8
+    out = dpsgd.d_step_grads_dpsgd(*args, clip=clip)          # the global batch, one process
+    Bl, nl = tr.B // R, n // R
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, Bl, tr.pac, dev, private=True, dp_mode='dpsgd',
+                     dp_sigma=sigma, dp_clip=clip, dist=dist, global_batch=tr.B)
+    eng.disc.load(dp)
+    eng.gen.load(gp)
+    per, flat = _flat_noise(eng)                              # same seed on every rank: the shared noise tensor
+    inj = {k: shard(full[k], r, R) for k in ('z', 'cond', 'mask', 'exp')}
+    inj['keep'] = [torch.cat([shard(m[b * n:(b + 1) * n], r, R) for b in range(3)]) for m in full['keep']]
+    inj['real'] = shard(full['real'], r, R)
+    inj['real_cond'] = shard(full['cond'][full['perm']], r, R)
+    inj['alpha'] = shard(full['alpha'], r, R)
+    inj['dp_noise'] = flat
+    eng.d_step(inj)
+    mine = slice(r * nl, (r + 1) * nl)
+    close(eng.norms, out['norms'][mine], what='rank %d: per-example gradient norms' % r)
+    close(eng.rowc[0:nl], out['factors'][mine], what='rank %d: clip factors' % r)
+    for k in tr.dkeys:          # the all-reduced clipped sums, scaled by the GLOBAL example count
+        close(eng.disc.G(k), out['grads'][k], rtol=2e-5, what='rank %d: clipped mean grad %s' % (r, k))
+    noisy = dpsgd.add_noise(out['grads'], per, sigma, clip, n)
+    dp2 = onets.apply_update(dp, noisy, {'t': 0, 'm': {}, 'v': {}})
+    for k in tr.dkeys:
+        close(eng.disc.P(k), dp2[k], what='rank %d: noised + Adam param %s' % (r, k))
+    chk = eng.disc.p.clone()
+    dist.allreduce(chk)
+    assert torch.equal(chk, eng.disc.p * R), 'replicas diverged: the noise was not added identically on every rank'
+
+
 def graph(dist, dev, mode):
     from golden_util import load
     from dp_cgans_amd.data_sampler import DataSampler
@@ -118,6 +170,55 @@ def graph(dist, dev, mode):
     dist.allreduce(chk)
     assert torch.equal(chk, a.disc.p * dist.world), 'replicas diverged'
     assert torch.isfinite(a.gen.p).all()
+
+
+def fallback(dist, dev, mode):
+    """GraphStep's capture-failure fallback: the first collective of the in-graph capture raises (test hook), the step
+    must warn, end that capture cleanly (branches were open) and capture again with eager collectives between graph
+    segments - bit-equal to the eager step."""
+    import warnings
+    from golden_util import load
+    from dp_cgans_amd import ops as _ops
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import GraphStep, StepEngine
+    assert dist.backend == 'nccl', 'the in-graph capture (and so its fallback) exists for RCCL only'
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    _ops.set_deterministic(True)
+
+    def make():
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=dist)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=9 + dist.rank)
+        return eng
+    a, b = make(), make()
+    for _ in range(4):
+        a.train_step(1)
+    gs = GraphStep(b, d_steps=1)
+    GraphStep.INJECT_CAPTURE_FAULT = True
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            gs.run()          # eager
+            gs.run()          # capture: in-graph attempt fails, segments follow
+        assert any('falling back to eager collectives' in str(x.message) for x in w), [str(x.message) for x in w]
+    finally:
+        GraphStep.INJECT_CAPTURE_FAULT = False
+    assert not gs.collectives_in_graph and len(gs.items) > 1
+    gs.run()
+    gs.run()
+    torch.cuda.synchronize()
+    assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p), 'the segment path after a failed capture differs from eager'
+    sa, sb = a.generator_state_dict(), b.generator_state_dict()
+    for k in sa:
+        assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
+    # and a fresh in-graph capture still works afterwards on the same streams
+    c = make()
+    gc = GraphStep(c, d_steps=1)
+    for _ in range(4):
+        gc.run()
+    torch.cuda.synchronize()
+    assert gc.collectives_in_graph and len(gc.items) == 1
+    assert torch.equal(a.disc.p, c.disc.p)
 
 
 def fused(dist, dev, mode):
@@ -175,8 +276,12 @@ def main():
     torch.cuda.set_device(dev)
     if mode == 'replay':
         replay(dist, dev)
+    elif mode == 'replay_dpsgd':
+        replay_dpsgd(dist, dev, sys.argv[2])
     elif mode == 'fused':
         fused(dist, dev, sys.argv[2])
+    elif mode == 'fallback':
+        fallback(dist, dev, sys.argv[2])
     else:
         graph(dist, dev, sys.argv[2])
     dist.barrier()

@@ -47,6 +47,13 @@ def test_two_ranks_replay_the_reference_trace():
     launch(['replay'])
 
 
+@pytest.mark.parametrize('clip', ['none', 'median', 'all'])
+def test_two_ranks_dpsgd_update_equals_the_single_process_oracle(clip):
+    """Per-rank clip factors + all-reduced clipped sums + one shared noise add == oracle/dpsgd.py on the global batch
+    (clip bound above every norm, at the median norm, below every norm)."""
+    launch(['replay_dpsgd', clip])
+
+
 @pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
 def test_two_ranks_graph_segments_equal_eager(mode):
     launch(['graph', mode])
@@ -68,6 +75,13 @@ def test_rccl_single_rank_graph_replay_equals_eager(mode, collectives):
     keeps them eager between graph segments (the fallback).  Both bit-equal to the eager step."""
     env = dict(RCCL1, DPCGAN_GRAPH_COLLECTIVES='1' if collectives == 'in-graph' else '0')
     launch(['graph', mode], world=1, extra_env=env)
+
+
+def test_rccl_capture_failure_falls_back_to_graph_segments():
+    """The first collective of the in-graph capture raises (test hook): GraphStep must warn, end that capture cleanly
+    although branches were open, re-capture in segments, reproduce the eager step bit for bit - and a later in-graph
+    capture on the same streams must still work."""
+    launch(['fallback', 'dpsgd'], world=1, extra_env=RCCL1)
 
 
 @pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
