@@ -807,6 +807,36 @@ __global__ __launch_bounds__(256, (BM == 128 ? 2 : 3)) void gemm_f32_kernel(Gemm
   DPC_STAMP_WALL(6);
 }
 
+// Grouped launch: up to DPC_GROUP_MAX INDEPENDENT products of one kernel variant (same operand layouts, 64x64 tiles)
+// as ONE grid - block b works on the product whose block range holds b.  The weight gradients of an update are such
+// a set (dy^T x per layer, all m-/n-contiguous): one launch instead of three parallel graph branches pays the
+// launch + prologue + epilogue ramp once and fills the CUs that a 128- or 176-block product leaves idle.
+#define DPC_GROUP_MAX 4
+struct GemmGroupArgs {
+  int count;
+  int start[DPC_GROUP_MAX + 1];      // block range of product i: [start[i], start[i+1])
+  GemmArgs g[DPC_GROUP_MAX];
+};
+
+template <bool A_KC, bool B_KC, bool KS>
+__global__ __launch_bounds__(256, 3) void gemm_group_kernel(GemmGroupArgs G) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Stage<64, A_KC, KS>::SIZE + 2 * Stage<64, B_KC>::SIZE];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < DPC_GROUP_MAX; ++k) i += (k < G.count && (int)blockIdx.x >= G.start[k]) ? 1 : 0;
+  const GemmArgs& g = G.g[i];
+  const int local = (int)blockIdx.x - G.start[i];
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int slot = gemm_xcd_slot(local, tiles * g.splitk);
+  const int split = slot / tiles;
+  int tile_m, tile_n;
+  gemm_tile_coords(g, slot - split * tiles, tile_m, tile_n);
+  const int k_begin = split * g.kchunk;
+  const int k_end = min(g.K, k_begin + g.kchunk);
+  if (k_begin >= k_end && split > 0) return;
+  gemm_segment<64, 64, A_KC, B_KC, 2, KS>(g, lds, tile_m * 64, tile_n * 64, k_begin, k_end, g.splitk > 1 || g.force_atomic, split == 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small products (few 64x64 tiles, short K: the K = 256 links of the discriminator's chains at batch 1024-3072)
 // are bound by a block's serial walk over K, not by the matrix cores: with 64-192 blocks on 256 CUs a block
@@ -984,8 +1014,18 @@ static void launch_tile(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st)
   else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, 2>), grid, block, 0, st, g);
 }
 
+// What gemm_one decided for a product that a grouped launch can take (64x64 tile kernel, nothing to do before or
+// after the launch): the argument block and the kernel variant.
+struct GemmPlan {
+  bool groupable;
+  bool a_kc, b_kc, ks;
+  GemmArgs g;
+};
+
 // One product.  Every tuning choice travels in the descriptor (splitk, tile): the library keeps no GEMM state.
-static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
+// With `plan`: a product the grouped launch can take is NOT launched - its plan is handed back instead.
+static int gemm_one(const dpc_gemm_desc& d, hipStream_t st, GemmPlan* plan = nullptr) {
+  if (plan) plan->groupable = false;
   const int M = d.M, N = d.N, K = d.K;
   const float beta = d.beta;
   const int epi = d.epi;
@@ -1119,6 +1159,12 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st) {
     g.beta = 1.f;   // accumulate into the zeroed C
   }
   GemmArgs full = g;
+  if (plan && bm == 64 && !deferred_epi) {       // (a split product's zero fill of C, if any, is on the stream already)
+    plan->groupable = true;
+    plan->a_kc = a_kc; plan->b_kc = b_kc; plan->ks = d.kscale != nullptr;
+    plan->g = g;
+    return DPC_OK;
+  }
   if (deferred_epi) { g.epi = EPI_NONE; g.bias = nullptr; g.gat = nullptr; }
   if (bm == 128) launch_tile<128, 128>(g, a_kc, b_kc, st);
   else launch_tile<64, 64>(g, a_kc, b_kc, st);
@@ -1134,6 +1180,51 @@ extern "C" int dpc_gemm_f32_ex(const dpc_gemm_desc* d, int count, void* stream) 
   for (int i = 0; i < count; ++i) {
     int rc = gemm_one(d[i], (hipStream_t)stream);
     if (rc != DPC_OK) return rc;
+  }
+  return DPC_OK;
+}
+
+template <bool A_KC, bool B_KC, bool KS>
+static void launch_group_variant(const GemmGroupArgs& G, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, KS>), dim3(blocks), dim3(256), 0, st, G);
+}
+
+// `count` INDEPENDENT products (no product reads what another of the set writes; products that ADD into one C must
+// ask for atomic accumulation).  Those that run on the 64x64 tile kernel with the same operand layouts share ONE
+// launch, up to four at a time; the others are issued on their own, in the order given.
+extern "C" int dpc_gemm_f32_group(const dpc_gemm_desc* d, int count, void* stream) {
+  DPC_CHECK_ARG(d && count >= 1 && count <= 64, "gemm_group: 1..64 descriptors");
+  hipStream_t st = (hipStream_t)stream;
+  GemmPlan plans[64];
+  for (int i = 0; i < count; ++i) {
+    int rc = gemm_one(d[i], st, &plans[i]);
+    if (rc != DPC_OK) return rc;
+  }
+  bool done[64];
+  for (int i = 0; i < count; ++i) done[i] = !plans[i].groupable;
+  for (int i = 0; i < count; ++i) {
+    if (done[i]) continue;
+    GemmGroupArgs G;
+    G.count = 0;
+    int blocks = 0;
+    for (int j = i; j < count && G.count < DPC_GROUP_MAX; ++j) {
+      if (done[j] || plans[j].a_kc != plans[i].a_kc || plans[j].b_kc != plans[i].b_kc || plans[j].ks != plans[i].ks) continue;
+      G.start[G.count] = blocks;
+      G.g[G.count] = plans[j].g;
+      blocks += plans[j].g.tiles_m * plans[j].g.tiles_n * plans[j].g.splitk;
+      ++G.count;
+      done[j] = true;
+    }
+    for (int k = G.count; k <= DPC_GROUP_MAX; ++k) G.start[k] = blocks;
+    const bool a_kc = plans[i].a_kc, b_kc = plans[i].b_kc, ks = plans[i].ks;
+    if (ks) {
+      if (b_kc) launch_group_variant<false, true, true>(G, blocks, st);
+      else launch_group_variant<false, false, true>(G, blocks, st);
+    } else if (a_kc && b_kc) launch_group_variant<true, true, false>(G, blocks, st);
+    else if (a_kc && !b_kc) launch_group_variant<true, false, false>(G, blocks, st);
+    else if (!a_kc && b_kc) launch_group_variant<false, true, false>(G, blocks, st);
+    else launch_group_variant<false, false, false>(G, blocks, st);
+    DPC_LAUNCH_CHECK();
   }
   return DPC_OK;
 }

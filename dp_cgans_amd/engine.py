@@ -207,7 +207,12 @@ class StepEngine(object):
         self._ar_hook = None
         self._ar_fault = None
         self._early_hook = None
-        self.early_at = os.environ.get('DPCGAN_EARLY_AT', 'd_forward')     # where train_step forks the generator update's forward
+        # where train_step forks the generator update's forward off the last discriminator update: 'd_forward' (in front
+        # of the discriminator's forward), 'd_forward_done' (behind its head kernel: the default - round 3, same-box A/B
+        # at T1M: 0.7235 / 0.7124 / 0.7574 / 0.7745 ms per step for d_forward / d_forward_done / d_chain_done /
+        # d_grads_done; with the faster products the lane no longer pays for slowing the discriminator's first-layer
+        # product and forward chain), 'd_chain_done' (in front of the weight gradients), 'd_grads_done'
+        self.early_at = os.environ.get('DPCGAN_EARLY_AT', 'd_forward_done')
         self._inline = False
         self.lr_g, self.wd_g, self.lr_d, self.wd_d = generator_lr, generator_decay, discriminator_lr, discriminator_decay
         d = self.dev
@@ -350,6 +355,7 @@ class StepEngine(object):
         self._early_open = False # the early stream holds work of _gen_forward_pair the main stream has not joined
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
+        self.group_dweights = os.environ.get('DPCGAN_GROUP_DW', '1') != '0'     # _d_back: the weight gradients as one grouped launch
         self.pair_forwards = True    # data-parallel train_step: one BatchNorm all-reduce per layer for both forwards
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
         self.perm = torch.zeros(B, device=d, dtype=torch.int64)
@@ -1004,7 +1010,7 @@ class StepEngine(object):
             self._disc_forward(3 * n, inj, rowscale=self.rowscale_d)
         self._loss_dirty[0] = True
         self._probe('d_forward_done')
-        if self._early_hook is not None:      # see train_step
+        if self._early_hook is not None and self.early_at not in ('d_chain_done', 'd_grads_done'):      # see train_step
             self._early_hook()
         # one downward chain for all 3n rows: first-order deltas (fake, real) and the penalty's u-chain
         self._disc_chain_down(3 * n, self.rowscale_d)
@@ -1047,6 +1053,41 @@ class StepEngine(object):
         # everything else beside it: the other layers' products, and ONE launch pair for all bias gradients and
         # the head layer's weight gradient (weighted column sums).
         self._probe('d_weight_grads')
+        if self._early_hook is not None and self.early_at == 'd_chain_done':
+            self._early_hook()
+        if gram and self.group_dweights and not self.deterministic:
+            # ONE launch for the independent weight-gradient products of the update (every layer's dy^T x and the
+            # penalty's u^T diag(f c) u: all m-/n-contiguous operands, one kernel variant - ops.gemm_group), the bias
+            # sums and the cond columns' sorted row sums on a branch beside it, then the one product that depends on
+            # the group (P1 W1 into dW1).  Before: three graph branches of 1 + 2 + (M-1) launches whose fixed costs
+            # and fork / join pairs the step paid per branch (phase 78 -> ~60 us in the T1M trace).
+            with self._fork(1) as part:
+                probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
+                probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
+                probs.append((self.ones_col, w_last[0:2 * n], d.G('seq.%d.bias' % (3 * M))))
+                for i in range(0, len(probs), 8):
+                    ops.colsum_multi(probs[i:i + 8], part, atomic=True)
+                if self.sparse_d:
+                    ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
+                                     rowscale=kscale[0:2 * n] if kscale is not None else None)
+            u = self.Dl[0][gp_rows]
+            ks2 = kscale[0:2 * n] if kscale is not None else None
+            seg_kw = dict(seg_c=1, seg=self.seg) if self.sparse_d else {}
+            descs = [ops.gemm_desc(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
+                                   kscale=ks2, splitk=0, tile=64, **seg_kw)]
+            prev = self.H[0]
+            for i in range(1, M):
+                descs.append(ops.gemm_desc(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0,
+                                           kscale=kscale, splitk=0, tile=64))
+                prev = self.H[i]
+            # (the d0 x d0 product over n rows: 16 tiles - cut along K so that it brings 128 blocks, not 16)
+            descs.append(ops.gemm_desc(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale, tile=64,
+                                       splitk=max(1, min(8, n // 128))))
+            ops.gemm_group(descs)
+            self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0)
+            self._join()
+            self._d_grads_tail(update, inj, sub)
+            return
         with self._fork(1) as part:
             probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
             probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
@@ -1085,6 +1126,11 @@ class StepEngine(object):
             # loss + penalty weight gradient in one product (rows scaled by their clip factor in DP-SGD mode)
             self._mm(self.Dl[0], self.Xd3, d.G('seq.0.weight'), trans_a=True, beta=1.0, kscale=kscale)
         self._join()
+        self._d_grads_tail(update, inj, sub)
+
+    def _d_grads_tail(self, update, inj, sub):
+        """What follows the weight gradients of a discriminator update: the cond columns' share, the Adam step."""
+        d = self.disc
         # The cond columns' sorted row sums join the flat gradient inside the Adam launch (_disc_update) - unless no
         # update follows, or the flat gradient is all-reduced first: then one transpose launch adds them here
         fused = update and self._adam_slices_d()
@@ -1093,6 +1139,8 @@ class StepEngine(object):
             ops.transpose_slices([(self.dW1cT[s * C:(s + 1) * C], gw[:, s * self.row + Dd:(s + 1) * self.row])
                                   for s in range(self.pac)], accumulate=True)
         self._probe('d_grads_done')
+        if self._early_hook is not None:          # (early_at == 'd_grads_done': beside the Adam launch only)
+            self._early_hook()
         if update:
             self._disc_update(inj, fused)
         if sub is None:

@@ -212,6 +212,17 @@ def gemm_run(descs):
                                        shapes=[d._shape for d in descs]),)
 
 
+def gemm_group(descs):
+    """INDEPENDENT products (list of gemm_desc results) in as few launches as their kernels allow (dpc_gemm_f32_group)."""
+    n = len(descs)
+    arr = (GemmDesc * n)(*descs)
+    L = lib()
+    L.call('dpc_gemm_f32_group', ctypes.byref(arr), n, _stream())
+    if L.log is not None:
+        L.log[-1] = L.log[-1] + (dict(flops=sum(d._flops for d in descs), bytes=sum(d._bytes for d in descs),
+                                       shapes=[d._shape for d in descs]),)
+
+
 def gemm(A, B, C, **kw):
     """C = epi(alpha * op(A) @ op(B) + bias) + beta * C on the matrix cores (fp32 MFMA); keywords of gemm_desc."""
     gemm_run([gemm_desc(A, B, C, **kw)])

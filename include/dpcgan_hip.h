@@ -123,6 +123,12 @@ typedef struct dpc_gemm_desc {
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */
 int dpc_gemm_f32_ex(const dpc_gemm_desc* d, int count, void* stream);
+/* `count` (1..64) INDEPENDENT products - none reads what another of the set writes; products that add into one C
+ * ask for `atomic` - in as few launches as their kernels allow: those that run on the 64x64 tile kernel with the
+ * same operand layouts (e.g. the weight gradients dy^T x of every layer of an update: autograd's per-layer
+ * addmm calls of loss.backward(), dp_cgan.py:652-655,720-721) share ONE grid, four at a time; the others are issued
+ * one by one in the order given.  Same results as dpc_gemm_f32_ex on each descriptor. */
+int dpc_gemm_f32_group(const dpc_gemm_desc* d, int count, void* stream);
 
 /* ---- generator output activation (DPCGANSynthesizer._apply_activate, dp_cgan.py:309-327) -- */
 /* spans: int32 [nspan][3] = (offset, dim, kind) kind 0 tanh, 1 softmax((x - log E)/tau), E~Exp(1)
