@@ -120,21 +120,18 @@ def main():
     elapsed = dist.max_float(time.perf_counter() - t0, dev)
     losses = eng.losses.cpu().tolist()
     rows = args.batch * dist.world * args.steps
+    args.workload = workload_string(args, table, dims)
     out = {
         'metric': 'DP-CGAN training rows/sec (D+G steps)', 'value': rows / elapsed, 'unit': 'rows/s',
         'n_gpus': dist.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s synthetic table (%d rows, %d encoded columns), per-GPU batch %d, '
-                               'pac %d, G/D dims %s, private=True (%s), discriminator_steps %d; BASELINE.json configs[%d]'
-                               % (args.table, table.shape[0], table.shape[1], args.batch, args.pac, dims,
-                                  'DP-SGD: per-example clip C=1 + Gaussian noise sigma=1' if args.dp_mode == 'dpsgd'
-                                  else 'reference hook-noise + weight clamp', args.d_steps,
-                                  {'T1M': 2, 'T10M': 3, 'TWIDE': 4}.get(args.table, 2)),
+        'config': {'workload': args.workload,
                    'global_batch': args.batch * dist.world, 'parallelism': 'dp%d' % dist.world,
                    'launch': 'eager' if args.no_graph else 'hipGraph replay (%d graph segment(s)%s)' % (
                        sum(1 for k, _ in (gstep.items or []) if k == 'graph'),
                        '' if not dist.active else (', RCCL all-reduces captured in the graph' if gstep.collectives_in_graph
                                                    else ', %d eager all-reduces between them' % sum(1 for k, _ in gstep.items if k != 'graph'))),
+                   'table_rows': int(table.shape[0]), 'd_steps': args.d_steps,
                    'data_dim': eng.Dd, 'cond_dim': eng.C, 'n_discrete': eng.nd, 'batch': args.batch, 'pac': args.pac,
                    'gen_dims': list(dims), 'disc_dims': list(dims), 'embedding_dim': eng.E,
                    'k0_compact': getattr(eng, 'K0x', eng.K0), 'disc_params': eng.disc.n, 'gen_params': eng.gen.n,
@@ -213,27 +210,37 @@ def source_sha():
     return h.hexdigest()[:12]
 
 
-def trace_figures(args):
-    """Per-kernel figures of the rocprofv3 kernel trace + PMC passes of THIS command (the step replayed as one
-    graph with its side branches: tools/kernel_roofline.py -> profiles/r02_kernel_roofline.json).  They are a
-    record of an earlier run, so they are only quoted when the sources they were taken with are the current
-    ones and the workload is the default one; otherwise None."""
-    path = os.path.join(ROOT, 'profiles', 'r02_kernel_roofline.json')
-    default_wl = (args.table == 'T1M' and args.rows is None and args.batch == 8192 and args.pac == 8
-                  and args.dims == '256,256' and args.d_steps == 1 and args.dp_mode == 'dpsgd')
-    if not default_wl or not os.path.exists(path):
-        return None
-    rec = json.load(open(path))
-    if rec.get('source_sha') != source_sha():
-        return None
-    # the same step traced as ONE chain (bench.py --serial): its kernels never overlap, so their durations are the
-    # kernels' own - the trace figure that the live chain replay below has to agree with
-    spath = os.path.join(ROOT, 'profiles', 'r02_kernel_roofline_serial.json')
-    if os.path.exists(spath):
-        srec = json.load(open(spath))
-        if srec.get('source_sha') == source_sha():
-            rec['serial'] = srec
-    return rec
+def workload_string(args, table, dims):
+    return ('%s synthetic table (%d rows, %d encoded columns), per-GPU batch %d, pac %d, G/D dims %s, private=True (%s), '
+            'discriminator_steps %d; BASELINE.json configs[%d]'
+            % (args.table, table.shape[0], table.shape[1], args.batch, args.pac, dims,
+               'DP-SGD: per-example clip C=1 + Gaussian noise sigma=1' if args.dp_mode == 'dpsgd'
+               else 'reference hook-noise + weight clamp', args.d_steps, {'T1M': 2, 'T10M': 3, 'TWIDE': 4}.get(args.table, 2)))
+
+
+def trace_figures(workload):
+    """Per-kernel figures of the rocprofv3 kernel trace + PMC passes of THIS command (the step replayed as one graph
+    with its side branches: tools/profile_round.sh, tools/kernel_roofline.py -> profiles/r03_kernel_roofline*.json,
+    one file per profiled workload).  They are records of earlier runs, so one is only quoted when it was taken on
+    this workload with the current sources; otherwise None."""
+    import glob
+    sha = source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_kernel_roofline*.json'))):
+        if path.endswith('_serial.json'):
+            continue
+        rec = json.load(open(path))
+        if rec.get('workload') != workload or rec.get('source_sha') != sha:
+            continue
+        # the same step traced as ONE chain (bench.py --serial): its kernels never overlap, so their durations are
+        # the kernels' own - the trace figure that the live chain replay below has to agree with
+        spath = path[:-len('.json')] + '_serial.json'
+        if os.path.exists(spath):
+            srec = json.load(open(spath))
+            if srec.get('source_sha') == sha and srec.get('workload') == workload:
+                rec['serial'] = srec
+        rec['file'] = os.path.basename(path)
+        return rec
+    return None
 
 
 def step_kernel_rooflines(eng, eager_step, args):
@@ -276,19 +283,22 @@ def step_kernel_rooflines(eng, eager_step, args):
         return 1e3 * e0.elapsed_time(e1) / (reps * copies)
 
     res = {}
-    trace = trace_figures(args)
+    trace = trace_figures(args.workload)
     tk = (trace or {}).get('kernels', {})
     # ---- the dominant kernel: the fp32 MFMA products (gemm_f32_kernel / gemm_ksplit_kernel, all variants)
-    gemms = [e for e in log if e[0] == 'dpc_gemm_f32_ex']
+    gemms = [e for e in log if e[0] in ('dpc_gemm_f32_ex', 'dpc_gemm_f32_group')]
     flops = sum(e[2]['flops'] for e in gemms)
-    nlaunch = sum(len(e[2]['shapes']) for e in gemms)
+    # launches: one per product, except that the products of a grouped call share a launch per kernel variant
+    # (operand layouts + k-scale: dpc_gemm_f32_group)
+    nprod = sum(len(e[2]['shapes']) for e in gemms)
+    nlaunch = sum(len(e[2]['shapes']) if e[0] == 'dpc_gemm_f32_ex' else len(set(sh[3:] for sh in e[2]['shapes'])) for e in gemms)
     alg_bytes = sum(e[2]['bytes'] for e in gemms) / nlaunch
     us = timed(gemms, copies=4)
     achieved = flops / (us * 1e-6) / 1e12
     if os.environ.get('DPC_GEMM_BREAKDOWN'):      # per-shape launch times of one step, to stderr
         for i, e in enumerate(gemms):
             t = timed([e], copies=20, reps=3)
-            m, n, k, ta, tb = e[2]['shapes'][0]
+            m, n, k, ta, tb = e[2]['shapes'][0][:5]
             sys.stderr.write('%2d M=%5d N=%5d K=%6d ta=%d tb=%d x%d  %7.1f us %6.1f TF/s\n'
                              % (i, m, n, k, ta, tb, len(e[2]['shapes']), t, 1e-6 * e[2]['flops'] / t))
     tg = tk.get('gemm')
@@ -299,7 +309,8 @@ def step_kernel_rooflines(eng, eager_step, args):
         'traffic_unit': 'HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of this workload: '
                         'tools/profile_round.sh, tools/kernel_roofline.py)',
         'algorithmic_bytes_per_launch': alg_bytes,
-        'kernel': 'gemm_f32_kernel + gemm_ksplit_kernel (all tile variants)', 'launches_per_step': nlaunch,
+        'kernel': 'gemm_f32_kernel + gemm_group_kernel + gemm_ksplit_kernel (all tile variants)', 'launches_per_step': nlaunch,
+        'products_per_step': nprod,
         'gflop_per_launch': flops / nlaunch / 1e9, 'avg_launch_us': us / nlaunch,
         'gflop_per_step': flops / 1e9, 'gemm_ms_per_step': us / 1e3,
         'method': "one step's GEMM launches issued again as one chain inside a captured graph (kernel time, no "
@@ -307,8 +318,8 @@ def step_kernel_rooflines(eng, eager_step, args):
         'in_graph_trace': None if not tg else {
             'achieved': tg['achieved'], 'frac': tg['frac'], 'avg_launch_us': tg['avg_us'],
             'launches_per_step': tg['launches_per_step'],
-            'source': 'profiles/%s (rocprofv3 --kernel-trace --stats of this command: the launches inside the '
-                      'replayed step graph, beside its side branches)' % trace['stats_csv']},
+            'source': 'profiles/%s + profiles/%s (rocprofv3 --kernel-trace --stats of this command: the launches '
+                      'inside the replayed step graph, beside its side branches)' % (trace['stats_csv'], trace['file'])},
     }
     ts = (trace or {}).get('serial', {}).get('kernels', {}).get('gemm')
     if ts:

@@ -197,7 +197,7 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     # multiplier matrices of the fused epilogues, the gathered rows
     d._bytes = 4.0 * (M * K + K * N + M * N * (1 + (beta != 0.0) + (aux_out is not None) + (aux_in is not None)
                                                 + 2 * (gat is not None)))
-    d._shape = (M, N, K, trans_a, trans_b)
+    d._shape = (M, N, K, bool(trans_a), bool(trans_b), kscale is not None)
     return d
 
 

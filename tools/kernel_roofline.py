@@ -33,42 +33,80 @@ from bench import FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, source_sha  # noqa: E402
 def family(name):
     n = name.replace('void ', '')
     n = n.split('(')[0]
-    if n.startswith('gemm_f32_kernel') or n.startswith('gemm_ksplit_kernel'):
+    if n.startswith('gemm_f32_kernel') or n.startswith('gemm_ksplit_kernel') or n.startswith('gemm_group_kernel'):
         return 'gemm'
     if n.startswith('at::native') or n.startswith('__amd_rocclr'):
         return 'torch fill / copy (zero pools)'
     return n.strip()
 
 
+def base_name(fam):
+    """Kernel family without its template arguments."""
+    return re.sub(r'<.*$', '', fam)
+
+
 def algorithmic_bytes_per_step(c):
-    """DESIGN.md section 4, per training step (1 discriminator + 1 generator update) and kernel family."""
+    """bytes every kernel family must move once per training step (d_steps discriminator updates +
+    1 generator update).  Keys: the family name as the trace prints it, or - where the template arguments do not change
+    the bytes - the name without them (``lookup`` tries both)."""
     B, Dd, C, pac = c['batch'], c['data_dim'], c['cond_dim'], c['pac']
     n = B // pac
     g, d = c['gen_dims'], c['disc_dims']
     K0x = c['k0_compact']
-    M = len(d)
-    clip = 4.0 * sum(3 * n * w for w in d + [1]) + 4.0 * (2 * n * K0x + sum(3 * n * w for w in d[:-1] + [d[-1]])) + 16.0 * n * d[0]
-    return {
-        'activate_fwd_small_kernel<false>': 8.0 * B * Dd,                 # raw in, activated out (D update's fake rows)
-        'activate_fwd_small_kernel<true>': 12.0 * B * Dd,                 # + the cond loss gradient written
-        'activate_bwd_tiled_kernel<true>': 16.0 * B * Dd,                 # y, dy, loss gradient in; d raw out
-        'persample_gram_all_kernel': clip,
+    ds = int(c.get('d_steps', 1))
+    nd = c['n_discrete']
+    E = c['embedding_dim']
+    d0, dl = d[0], d[-1]
+    clip = 4.0 * sum(3 * n * w for w in d + [1]) + 4.0 * (2 * n * K0x + sum(3 * n * w for w in d[:-1] + [d[-1]])) + 16.0 * n * d0
+    rows = c.get('table_rows', 0)
+    words = (rows + 63) // 64
+    S = 64
+    act_f, act_t, act_b = 8.0 * B * Dd, 12.0 * B * Dd, 16.0 * B * Dd
+    m = {
+        # raw output in, activated out (the discriminator updates' fake rows); + the cond-loss gradient written; backward
+        'activate_fwd_small_kernel<false>': ds * act_f, 'activate_fwd_tiled_kernel<false>': ds * act_f,
+        'activate_fwd_wide_kernel<false>': ds * act_f,
+        'activate_fwd_small_kernel<true>': act_t, 'activate_fwd_tiled_kernel<true>': act_t, 'activate_fwd_wide_kernel<true>': act_t,
+        'activate_bwd_tiled_kernel': act_b, 'activate_bwd_wide_kernel': act_b,
+        'persample_gram_all_kernel': ds * clip,
         # (+ the cond slices' transposed gradient addend in and transposed copy out, moved by the same launch)
-        'adam_kernel_disc': 28.0 * c['disc_params'] + 8.0 * pac * C * d[0],
+        'adam_kernel_disc': ds * (28.0 * c['disc_params'] + 8.0 * pac * C * d0),
         'adam_kernel_gen': 28.0 * c['gen_params'] + 8.0 * C * (sum(g) + Dd),
-        'row_gather_kernel': 8.0 * B * Dd,
-        'bn_relu_fwd_fused_kernel': 2 * sum(8.0 * B * w for w in g),     # both generator forwards of the step
+        'row_gather_kernel': ds * 8.0 * B * Dd,
+        # k-th set bit of bitmap_a & bitmap_b: the S superblock counts, then ONE superblock of both bitmaps
+        'row_select_kernel': ds * B * (4.0 * S + 2 * 8.0 * ((words + S - 1) // S)),
+        'perm_feistel_kernel': ds * 8.0 * B,
+        'bn_relu_fwd_fused_kernel': (ds + 1) * sum(8.0 * B * w for w in g),      # every generator forward of the step
         'bn_relu_bwd_fused_kernel': sum(16.0 * B * w for w in g),
         'colreduce_kernel<2>': sum(12.0 * B * w for w in g),
-        'disc_out_kernel': 12.0 * (3 * n + n) * d[-1],
-        'gp_gram_rows_kernel': 16.0 * n * d[0],
-        'disc_first_act_kernel<true>': 4.0 * d[0] * ((2 * n + 2 * 3 * n + 2 * n) + (n + 2 * n)),
-        'condvec_pair_kernel': 2 * (4.0 * B * 2 + 4.0 * B * c['n_discrete']),
-        # both updates' inputs: cond vector twice (own copy + the generator-input columns), mask, latent batch, and
-        # the zero fill of the two accumulator pools (flat gradients, transposed cond-column gradients, Gram products)
-        'step_inputs_kernel': 2 * (8.0 * B * C + 4.0 * B * c['n_discrete'] + 4.0 * B * c['embedding_dim'])
-                              + 4.0 * (c['disc_params'] + c['gen_params'] + 2 * d[0] * d[0] + pac * C * d[0] + C * (sum(g) + Dd)),
+        'disc_out_kernel': 12.0 * (ds * 3 * n + n) * dl,
+        'gp_gram_rows_kernel': ds * 16.0 * n * d0,
+        'disc_first_act_kernel': 4.0 * d0 * (ds * ((2 * n + 2 * 3 * n + 2 * n) + 2 * pac * 2 * n) + (n + 2 * n) + 2 * pac * n),
+        'condvec_pair_kernel': (ds + 1) * (4.0 * B * 2 + 4.0 * B * nd),
+        # the updates' inputs: cond vector twice (own copy + the generator-input columns), mask, latent batch, and the
+        # zero fill of the accumulator pools (flat gradients, transposed cond-column gradients, Gram products)
+        'step_inputs_kernel': (ds + 1) * (8.0 * B * C + 4.0 * B * nd + 4.0 * B * E)
+                              + 4.0 * (ds * (c['disc_params'] + 2 * d0 * d0 + pac * C * d0) + c['gen_params'] + C * (sum(g) + Dd)),
+        # cond columns of the weight gradients: one delta row read per (row, hot id) pair - 4B pairs of d0 floats in a
+        # discriminator update, 2B pairs per generator Linear - plus one atomic row per id change (~pairs / 64 + C rows)
+        'hot_rows_sum_kernel': 4.0 * (ds * (4 * B * d0 + (4 * B // 64 + pac * C) * d0)
+                                      + sum(2 * B * w + (2 * B // 64 + C) * w for w in g + [Dd])),
+        # counting sort of the (row, id) pairs: ids read twice (count, place), (row, id) written, the per-id counters
+        'hot_sort_kernel': 4.0 * (ds * (3 * 4 * B + 2 * pac * C) + 3 * 2 * B + 2 * C),
+        # bias gradients + the head's weight gradient: every delta matrix of the update read once
+        'colsum_multi_partial_kernel': 4.0 * (ds * (sum(2 * n * w for w in d) + 3 * n * dl + 2 * n) + B * (sum(g) + Dd)),
+        'colsum_multi_finish_kernel': 8.0 * 64 * (ds * (sum(d) + dl + 1) + sum(g) + Dd),
+        'colreduce_finish_kernel': 8.0 * 4 * 2 * sum(g) * 2,
+        'transpose_slices_kernel': 8.0 * (ds * pac * C * d0 + C * (sum(g) + Dd)),
+        'rng_advance_kernel': 64.0,
     }
+    return m
+
+
+def lookup(alg, fam):
+    if fam in alg:
+        return alg[fam]
+    return alg.get(base_name(fam))
 
 
 def main():
@@ -117,12 +155,15 @@ def main():
             ent.update(bound='mfma', gflop_per_step=gf, achieved=ach, unit='TFLOP/s', peak=FP32_MFMA_PEAK_TFLOPS,
                        frac=ach / FP32_MFMA_PEAK_TFLOPS,
                        algorithmic_bytes_per_launch=bench['roofline']['algorithmic_bytes_per_launch'])
-        elif fam in alg:
-            ach = alg[fam] / (us / steps * 1e-6) / 1e9
-            ent.update(bound='hbm', algorithmic_bytes_per_step=alg[fam], achieved=ach, unit='GB/s', peak=HBM_PEAK_GBS,
-                       frac=ach / HBM_PEAK_GBS)
+        elif lookup(alg, fam) is not None:
+            by = lookup(alg, fam)
+            ach = by / (us / steps * 1e-6) / 1e9
+            ent.update(bound='hbm', algorithmic_bytes_per_step=by, algorithmic_bytes_per_launch=by / (cnt / steps), achieved=ach,
+                       unit='GB/s', peak=HBM_PEAK_GBS, frac=ach / HBM_PEAK_GBS)
+            if by / (cnt / steps) < 1e6:      # (said only where the modelled bytes really are small)
+                ent['note'] = 'under 1 MB per launch: bounded by launch + dependency latency, not by bandwidth'
         else:
-            ent.update(bound='latency / index work', note='a few hundred KB per launch: bounded by launch + dependency latency')
+            ent.update(bound='unmodelled', note='no byte model for this kernel (tools/kernel_roofline.py)')
         kernels[fam] = ent
     if a.fetch and a.write:
         def per_kernel(path):
@@ -131,6 +172,21 @@ def main():
                 if family(r['Kernel_Name']) == 'gemm':
                     v.append(float(r['Counter_Value']))
             return v
+        # every family's HBM-side traffic per launch (adam: both launches' average)
+        def by_family(path):
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(path)):
+                f = family(r['Kernel_Name'])
+                acc[f][0] += float(r['Counter_Value'])
+                acc[f][1] += 1
+            return {f: v[0] / v[1] for f, v in acc.items()}
+        ff, fw = by_family(a.fetch), by_family(a.write)
+        for fam, ent in kernels.items():
+            key = 'adam_kernel<true>' if fam.startswith('adam_kernel_') else fam
+            if fam != 'gemm' and key in ff and key in fw:
+                ent['traffic_bytes_per_launch'] = (2.0 * ff[key] + fw[key]) * 1024.0
+                if 'algorithmic_bytes_per_launch' in ent and ent['algorithmic_bytes_per_launch'] > 0:
+                    ent['traffic_over_algorithmic'] = ent['traffic_bytes_per_launch'] / ent['algorithmic_bytes_per_launch']
         gf, gw = per_kernel(a.fetch), per_kernel(a.write)
         kernels['gemm'].update(
             traffic_bytes_per_launch=(2.0 * sum(gf) / len(gf) + sum(gw) / len(gw)) * 1024.0,
