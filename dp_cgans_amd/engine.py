@@ -1071,20 +1071,22 @@ class StepEngine(object):
                     ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
                                      rowscale=kscale[0:2 * n] if kscale is not None else None)
             u = self.Dl[0][gp_rows]
+            with self._fork(0):
+                # the penalty's share of dW1, (u^T diag(f c) u) W1: two small dependent products beside the group (the
+                # d0 x d0 one over n rows has 16 tiles - cut along K so that it brings 128 blocks, not 16); it ADDS to
+                # dW1 while the group's first product does: atomics on both sides
+                self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale, tile=64, splitk=max(1, min(8, n // 128)))
+                self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0, atomic=True)
             ks2 = kscale[0:2 * n] if kscale is not None else None
             seg_kw = dict(seg_c=1, seg=self.seg) if self.sparse_d else {}
             descs = [ops.gemm_desc(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
-                                   kscale=ks2, splitk=0, tile=64, **seg_kw)]
+                                   kscale=ks2, splitk=0, tile=64, atomic=True, **seg_kw)]
             prev = self.H[0]
             for i in range(1, M):
                 descs.append(ops.gemm_desc(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0,
                                            kscale=kscale, splitk=0, tile=64))
                 prev = self.H[i]
-            # (the d0 x d0 product over n rows: 16 tiles - cut along K so that it brings 128 blocks, not 16)
-            descs.append(ops.gemm_desc(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale, tile=64,
-                                       splitk=max(1, min(8, n // 128))))
             ops.gemm_group(descs)
-            self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0)
             self._join()
             self._d_grads_tail(update, inj, sub)
             return
@@ -1273,6 +1275,10 @@ class StepEngine(object):
         # would share the CUs and the chain that everything else waits for (dHg -> BatchNorm backward -> ..)
         # would take twice as long; from here on it runs beside that chain's small kernels
         self._probe('g_dhg_done')
+        # (measured and dropped in round 3: the Residual blocks' Linear-bias gradients as atomics out of the BatchNorm-
+        # backward launches and the output layer's column sum on this branch, so that no column-sum launch is left in
+        # front of the Adam step - 0.693 -> 0.701 ms: 256 row chunks adding to the same 256 addresses serialise in L2
+        # and lengthen the two BatchNorm-backward launches of the critical chain by more than the launch they save)
         with self._fork(0):
             self._probe('g_out_dweight_branch')
             self._gen_dweight(c, L, self.dfake)
