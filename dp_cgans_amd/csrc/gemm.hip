@@ -71,6 +71,10 @@ struct GemmArgs {
   int stat_n;
   int stat_slots;        // the accumulators are [stat_slots][2][stat_n]: tile row t adds into slot t % stat_slots (fewer atomics per address)
   int force_atomic;      // add the result to C with fp32 atomics even without split-K (another product adds to C meanwhile)
+  // EPI_LEAKY_DROPOUT only, optional: seed_out[m, n] = (seed_row[m] * seed_col[n]) * slope[m, n] - the seed of the
+  // backward chain of the discriminator's LAST hidden layer (delta = rowscale * w_head * slope: what the head kernel
+  // writes otherwise), so that the chain's first product follows this one directly
+  float* seed_out; int64_t ld_seed; const float* seed_row; const float* seed_col;
 };
 
 // stored index minus compact index
@@ -708,6 +712,14 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* lds, cons
               const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
               if (ok[e8]) g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope[e8];
             }
+            if (g.seed_out) {
+              const float wc = g.seed_col[col];
+#pragma unroll
+              for (int e8 = 0; e8 < 8; ++e8) {
+                const int row = rbase + (e8 & 3) + 8 * (e8 >> 2);
+                if (ok[e8]) g.seed_out[(int64_t)row * g.ld_seed + col] = (g.seed_row[min(row, mlast)] * wc) * slope[e8];
+              }
+            }
           } else if (g.epi == EPI_MUL) {
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) v[e8] *= aux[e8];
@@ -951,6 +963,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmArgs g) {
       else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
       const float slope = (x > 0.f ? 1.f : g.leak) * keep * 2.f;
       g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+      if (g.seed_out) g.seed_out[(int64_t)row * g.ld_seed + col] = (g.seed_row[row] * g.seed_col[col]) * slope;
       x *= slope;
     } else if (g.epi == EPI_MUL) {
       x *= aux4[q];
@@ -990,6 +1003,7 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(GemmArgs g) {
       else keep = (dpc_draw_u32(g.rng, g.site, (uint64_t)row * g.N + col) >> 31) ? 1.f : 0.f;
       float slope = (v > 0.f ? 1.f : g.leak) * keep * 2.f;
       g.aux_out[(int64_t)row * g.ld_aux_out + col] = slope;
+      if (g.seed_out) g.seed_out[(int64_t)row * g.ld_seed + col] = (g.seed_row[row] * g.seed_col[col]) * slope;
       v *= slope;
     } else if (g.epi == EPI_MUL) {
       v *= g.aux_in[(int64_t)row * g.ld_aux_in + col];
@@ -1069,6 +1083,9 @@ static int gemm_one(const dpc_gemm_desc& d, hipStream_t st, GemmPlan* plan = nul
                             d.ld_bn_y >= d.stat_n && d.ld_bn_z >= d.stat_n && (beta == 0.f || beta == 1.f)),
                 "gemm: BatchNorm-backward statistics need colstat, y, z, mean, invstd and 1 <= stat_n <= N");
   g.force_atomic = d.atomic ? 1 : 0;
+  g.seed_out = d.seed_out; g.ld_seed = d.ld_seed; g.seed_row = d.seed_row; g.seed_col = d.seed_col;
+  DPC_CHECK_ARG(!d.seed_out || (epi == EPI_LEAKY_DROPOUT && d.seed_row && d.seed_col && d.ld_seed >= N),
+                "gemm: the chain seed goes with the LeakyReLU + Dropout epilogue and needs seed_row, seed_col and ld_seed >= N");
   DPC_CHECK_ARG(!d.atomic || (beta == 1.f && epi == EPI_NONE && !d.bias && !d.gat && !d.colstat && d.tile != 32 && d.tile != 324),
                 "gemm: atomic accumulation needs beta == 1 and a plain product");
   DPC_CHECK_ARG(!d.colstat || (epi == EPI_NONE && !d.seg_c && (d.splitk == 0 || d.splitk == 1)),

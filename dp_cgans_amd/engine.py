@@ -205,6 +205,8 @@ class StepEngine(object):
             weight_clip = 0.01 if self.dp_mode == 'reference' else 0.0
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
+        self._head_pending = None
+        self.want_interp_scores = False      # compute the discriminator's scores of the penalty's interpolates (diagnostic: _defer_head)
         self._ar_fault = None
         self._early_hook = None
         # where train_step forks the generator update's forward off the last discriminator update: 'd_forward' (in front
@@ -356,6 +358,7 @@ class StepEngine(object):
         self._so = 0             # Philox call-site offset of the update being issued (64 * its index in the step)
         self.concurrent = True
         self.group_dweights = os.environ.get('DPCGAN_GROUP_DW', '1') != '0'     # _d_back: the weight gradients as one grouped launch
+        self.seed_in_epilogue = os.environ.get('DPCGAN_SEED_EPI', '1') != '0'   # _disc_forward: the chain seed out of the last hidden layer's product
         self.pair_forwards = True    # data-parallel train_step: one BatchNorm all-reduce per layer for both forwards
         self.part_loss = torch.zeros(2048, device=d, dtype=torch.float64)
         self.perm = torch.zeros(B, device=d, dtype=torch.int64)
@@ -823,16 +826,24 @@ class StepEngine(object):
                              stacked=False, clear=True)
             x = self.H[0][rs]
             first = 1
+        w_head = d.P('seq.%d.weight' % (3 * M))
+        seeded = rowscale is not None and first < M and self.seed_in_epilogue
         for i in range(first, M):
+            # the LAST hidden layer's product also writes the seed of the backward chain, rowscale * w_head * slope: the
+            # chain then follows it directly and the head kernel (y alone: only the loss scalars read it) leaves the
+            # critical path for a branch
+            seed = (self.Dl[i][rs], rowscale[0:rows], w_head.view(-1)) if seeded and i == M - 1 else None
             self._mm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i][rs], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i][rs], keep=keeps[i] if keeps else None,
-                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
+                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK, seed=seed)
             x = self.H[i][rs]
         y = self.y[rs] if y is None else y
         if rowscale is None:
-            ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), y)
+            ops.disc_out_fwd(x, w_head, d.P('seq.%d.bias' % (3 * M)), y)
+        elif seeded:
+            self._defer_head(x, y, rows)
         else:
-            ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), y, rowscale=rowscale,
+            ops.disc_out_fwd(x, w_head, d.P('seq.%d.bias' % (3 * M)), y, rowscale=rowscale,
                              slope=self.S[M - 1][rs], delta=self.Dl[M - 1][rs])
 
     def _disc_forward_stacked(self, inj):
@@ -849,13 +860,43 @@ class StepEngine(object):
                          dict(sel_a=self.cd.sel, sel_b=self.sel_real) if self.sparse_d else None,
                          alpha_inj=inj.get('alpha'), site_alpha=ops.SITE_ALPHA + self._so, clear=self.dp_mode != 'dpsgd')
         x = self.H[0]
+        w_head = d.P('seq.%d.weight' % (3 * M))
+        seeded = M > 1 and self.seed_in_epilogue
         for i in range(1, M):
+            seed = (self.Dl[i], self.rowscale_d, w_head.view(-1)) if seeded and i == M - 1 else None      # (see _disc_forward)
             self._mm(x, d.P('seq.%d.weight' % (3 * i)), self.H[i], trans_b=True, bias=d.P('seq.%d.bias' % (3 * i)),
                      epi=ops.EPI_LEAKY_DROPOUT, aux_out=self.S[i], keep=keeps[i] if keeps else None,
-                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK)
+                     rng=self.rng, site=ops.SITE_DROP0 + i + self._so, leak=LEAK, seed=seed)
             x = self.H[i]
-        ops.disc_out_fwd(x, d.P('seq.%d.weight' % (3 * M)), d.P('seq.%d.bias' % (3 * M)), self.y,
-                         rowscale=self.rowscale_d, slope=self.S[M - 1], delta=self.Dl[M - 1])
+        if seeded:
+            self._defer_head(x, self.y, 3 * self.n)
+        else:
+            ops.disc_out_fwd(x, w_head, d.P('seq.%d.bias' % (3 * M)), self.y,
+                             rowscale=self.rowscale_d, slope=self.S[M - 1], delta=self.Dl[M - 1])
+
+    def _defer_head(self, x, y, rows):
+        """Leave the head y = h w_head + b of ``rows`` rows to the next side branch (_flush_head).  In the discriminator
+        update's stacked pass (3n rows) the penalty's v-chain later overwrites the interpolates' rows of h, and nothing
+        but a diagnostic reads their scores: they are computed - at once, on the main stream - only when
+        ``want_interp_scores`` is set (the golden-trace tests compare them), otherwise y[2n:3n] is left as it was."""
+        n = self.n
+        if rows == 3 * n:
+            if self.want_interp_scores:
+                M = self.M
+                ops.disc_out_fwd(x[2 * n:3 * n], self.disc.P('seq.%d.weight' % (3 * M)), self.disc.P('seq.%d.bias' % (3 * M)),
+                                 y[2 * n:3 * n])
+            x, y = x[0:2 * n], y[0:2 * n]
+        self._head_pending = (x, y)
+
+    def _flush_head(self):
+        """The discriminator head y = h w_head + b of the latest forward, left out of the main chain by the seed epilogue
+        (_disc_forward): issued where the caller has a side branch open anyway - a fork of its own cost more than the
+        kernel (0.695 -> 0.737 ms per step with its own fork / join pair)."""
+        if self._head_pending is not None:
+            x, y = self._head_pending
+            self._head_pending = None
+            M = self.M
+            ops.disc_out_fwd(x, self.disc.P('seq.%d.weight' % (3 * M)), self.disc.P('seq.%d.bias' % (3 * M)), y)
 
     def score_real_rows(self, inj=None, rows=None):
         """Discriminator output [rows / pac, 1] on freshly sampled real rows with their cond vectors
@@ -1070,6 +1111,7 @@ class StepEngine(object):
                 if self.sparse_d:
                     ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
                                      rowscale=kscale[0:2 * n] if kscale is not None else None)
+                self._flush_head()
             u = self.Dl[0][gp_rows]
             with self._fork(0):
                 # the penalty's share of dW1, (u^T diag(f c) u) W1: two small dependent products beside the group (the
@@ -1100,6 +1142,7 @@ class StepEngine(object):
                 # cond columns of dW1: sums of the (clip-scaled) delta rows by hot id, transposed into place below
                 ops.hot_rows_sum(self.Dl[0][0:2 * n], self.order_d, self.sid_d, self.n_items_d, self.dW1cT,
                                  rowscale=kscale[0:2 * n] if kscale is not None else None)
+            self._flush_head()
             # the other layers' products behind the small kernels of this branch: branch 0 carries the penalty's two
             # products, the main stream the K0-wide one - three lanes of about equal length (0.795 -> 0.786 ms per
             # step against all products on branch 0)
@@ -1133,6 +1176,7 @@ class StepEngine(object):
     def _d_grads_tail(self, update, inj, sub):
         """What follows the weight gradients of a discriminator update: the cond columns' share, the Adam step."""
         d = self.disc
+        self._flush_head()       # (no-op when a branch has taken it)
         # The cond columns' sorted row sums join the flat gradient inside the Adam launch (_disc_update) - unless no
         # update follows, or the flat gradient is all-reduced first: then one transpose launch adds them here
         fused = update and self._adam_slices_d()
@@ -1282,6 +1326,7 @@ class StepEngine(object):
         with self._fork(0):
             self._probe('g_out_dweight_branch')
             self._gen_dweight(c, L, self.dfake)
+            self._flush_head()
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])

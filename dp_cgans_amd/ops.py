@@ -96,7 +96,9 @@ class GemmDesc(ctypes.Structure):
                 ('seg_pad', ctypes.c_int32), ('seg_stride', ctypes.c_int64), ('colstat', ctypes.c_void_p),
                 ('atomic', ctypes.c_int32), ('bn_y', ctypes.c_void_p), ('ld_bn_y', ctypes.c_int64),
                 ('bn_z', ctypes.c_void_p), ('ld_bn_z', ctypes.c_int64), ('bn_mean', ctypes.c_void_p),
-                ('bn_invstd', ctypes.c_void_p), ('stat_n', ctypes.c_int32), ('stat_slots', ctypes.c_int32)]
+                ('bn_invstd', ctypes.c_void_p), ('stat_n', ctypes.c_int32), ('stat_slots', ctypes.c_int32),
+                ('seed_out', ctypes.c_void_p), ('ld_seed', ctypes.c_int64), ('seed_row', ctypes.c_void_p),
+                ('seed_col', ctypes.c_void_p)]
 
 
 def _addr(t):
@@ -132,7 +134,7 @@ def _mat_strides(t, trans):
 
 def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, epi=EPI_NONE, aux_out=None,
               aux_in=None, keep=None, rng=None, site=0, leak=0.2, splitk=None, kscale=None, tile=0, gat=None, gidx=None,
-              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False, bn_back=None, stat_slots=1):
+              seg_b=0, seg_c=0, seg=None, colstat=None, atomic=False, bn_back=None, stat_slots=1, seed=None):
     """dpc_gemm_desc for C = epi(alpha * op(A) @ op(B) + bias [+ gat rows]) + beta * C.
     ``seg`` = (seg_len, seg_pad, seg_stride) with ``seg_b`` (1: along K of a k-contiguous B, 2: along N of an
     n-contiguous B) and / or ``seg_c`` (along N of C): B's (C's) mapped axis is given in COMPACT length by A / C
@@ -172,6 +174,13 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     d.rng, d.site, d.splitk, d.tile, d.kscale = _addr(rng), site, int(splitk), int(tile), _addr(kscale)
     d.gat, d.ldg, d.gidx = _addr(gat), _ld(gat) if gat is not None else 0, _addr(gidx)
     d.atomic = 1 if atomic else 0
+    if seed is not None:        # (seed_out [M, N], rowscale [M], w_head [N]): the backward chain's seed beside the slope
+        so, sr, sc = seed
+        for t, nm in ((so, 'seed_out'), (sr, 'seed_row'), (sc, 'seed_col')):
+            _chk(t, torch.float32, nm)
+        if so.shape[0] != M or so.shape[1] != N or sr.numel() != M or sc.numel() != N or not sr.is_contiguous() or not sc.is_contiguous():
+            raise ValueError('gemm: seed = (seed_out [M, N], rowscale [M], w_head [N])')
+        d.seed_out, d.ld_seed, d.seed_row, d.seed_col = _addr(so), _ld(so), _addr(sr), _addr(sc)
     if colstat is not None:
         _chk(colstat, torch.float64, 'colstat')
         ncs = N
@@ -195,7 +204,7 @@ def gemm_desc(A, B, C, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=N
     d._flops = 2.0 * M * N * K
     # bytes the product must move once: both operands, C (read as well when it is accumulated into), the slope /
     # multiplier matrices of the fused epilogues, the gathered rows
-    d._bytes = 4.0 * (M * K + K * N + M * N * (1 + (beta != 0.0) + (aux_out is not None) + (aux_in is not None)
+    d._bytes = 4.0 * (M * K + K * N + M * N * (1 + (beta != 0.0) + (aux_out is not None) + (aux_in is not None) + (seed is not None)
                                                 + 2 * (gat is not None)))
     d._shape = (M, N, K, bool(trans_a), bool(trans_b), kscale is not None)
     return d

@@ -119,6 +119,10 @@ typedef struct dpc_gemm_desc {
   const float* bn_y; int64_t ld_bn_y; const float* bn_z; int64_t ld_bn_z; const float* bn_mean; const float* bn_invstd;
   int32_t stat_n;
   int32_t stat_slots;
+  /* epi 1 only, optional: seed_out[m,n] = (seed_row[m] * seed_col[n]) * slope[m,n] - for the discriminator's LAST
+   * hidden layer the seed of the backward chain, rowscale * w_head * slope (what dpc_disc_out_fwd's `delta` is):
+   * the chain's first product can then follow the forward product directly (dp_cgan.py:629-631,652-655) */
+  float* seed_out; int64_t ld_seed; const float* seed_row; const float* seed_col;
 } dpc_gemm_desc;
 /* `count` (1..64) products, descriptors in host memory, issued in order on `stream`.  The library keeps no
  * GEMM state: two callers in one process cannot disturb each other's tiling or reproducibility. */

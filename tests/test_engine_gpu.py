@@ -41,6 +41,7 @@ from golden_util import AdamAwareCompare  # noqa: E402,F401  (shared with the CP
 def make_engine(tr, device='cuda:0'):
     from dp_cgans_amd.engine import StepEngine
     eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, tr.B, tr.pac, device, private=bool(tr.private))
+    eng.want_interp_scores = True      # the trace holds the discriminator's scores of the interpolates too (a diagnostic in the step)
     first_d, first_g = tr.kinds.index('D'), tr.kinds.index('G')
     eng.disc.load(tr.params(first_d, 'p_before'))
     eng.gen.load(tr.params(first_g, 'p_before'))
