@@ -1452,6 +1452,10 @@ class StepEngine(object):
             self._g_back({}, True, d_steps)
         else:
             self.g_step(sub=d_steps)
+        # (measured and dropped in round 3: this bookkeeping inside the generator's Adam launch - every block takes a
+        # ticket when done and the last one bumps the counters, so the one-thread launch goes away: 0.6846 -> 0.688 ms
+        # per step.  The returning atomic at the end of each of ~600 short-lived blocks costs the launch more than the
+        # 4 us node it removes.)
         ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
 
     # ------------------------------------------------------------------------------------------

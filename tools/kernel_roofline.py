@@ -9,7 +9,7 @@ usage: kernel_roofline.py --trace <bench_kernel_trace.csv> --bench <stdout of th
                           --stats-name <file name of the kernel_stats.csv as committed under profiles/>
                           [--fetch <counter_collection.csv> --write <counter_collection.csv>] --out profiles/r02_kernel_roofline.json
 
-The trace is cut into training steps at rng_advance_kernel (the last node of the step graph); the `steps` timed
+The trace is cut into training steps at each step's last adam_kernel launch (tools/trace_steps.py); the `steps` timed
 replays of the bench run (after its warm-up) are averaged: launches per step and average duration of every kernel
 as it runs INSIDE the step graph, beside the graph's side branches.  Algorithmic work per kernel follows DESIGN.md
 section 4 (bytes each kernel must move once, flops of the products); achieved = work / time, frac = achieved / peak
@@ -27,7 +27,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench import FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, source_sha  # noqa: E402
+from trace_steps import step_ends  # noqa: E402
 
 
 def family(name):
@@ -129,7 +131,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if 'rng_advance_kernel' in r[2]]
+    ends = step_ends([r[2] for r in rows], cfg.get('d_steps', 1))
     warm, steps = max(bench['warmup'], 2), bench['steps']
     # step k of the run = rows (ends[k-1], ends[k]]; the timed replays are steps warm .. warm+steps-1
     per = collections.defaultdict(lambda: [0, 0.0])
@@ -137,12 +139,10 @@ def main():
     for k in range(warm, warm + steps):
         lo, hi = ends[k - 1] + 1, ends[k] + 1
         span_us += (rows[hi - 1][1] - rows[lo - 1][1]) / 1e3
-        seen_adam = 0
-        for s, e, name in rows[lo:hi]:
+        for j, (s, e, name) in enumerate(rows[lo:hi]):
             fam = family(name)
             if fam.startswith('adam_kernel'):
-                fam = 'adam_kernel_disc' if seen_adam == 0 else 'adam_kernel_gen'
-                seen_adam += 1
+                fam = 'adam_kernel_gen' if lo + j == hi - 1 else 'adam_kernel_disc'    # the step's last kernel
             per[fam][0] += 1
             per[fam][1] += (e - s) / 1e3
     alg = algorithmic_bytes_per_step(cfg)
