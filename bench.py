@@ -90,9 +90,17 @@ def main():
     torch.cuda.set_device(dev)
     dims = tuple(int(x) for x in args.dims.split(','))
 
-    t0 = time.time()
+    def progress(what):
+        # one line per phase on stderr: a wide workload spends minutes between start and the JSON line
+        if dist.rank == 0:
+            sys.stderr.write('bench.py: %s (%.1f s)\n' % (what, time.time() - t_start))
+            sys.stderr.flush()
+
+    t_start = t0 = time.time()
     table, span = build_encoded_table(args.table, dev, n_rows=args.rows)
+    progress('table encoded')
     sampler = DataSampler(table, span, device=dev, seed=17 + dist.rank)
+    progress('sampler tables built')
     eng = StepEngine(span, 128, dims, dims, args.batch, args.pac, dev, private=True, seed=0, dist=dist,
                      dp_mode=args.dp_mode, dp_sigma=1.0, dp_clip=1.0)
     eng.sampler = sampler
@@ -109,6 +117,7 @@ def main():
     for _ in range(max(args.warmup, 2)):      # (first call eager, second captures the graph)
         step()
     torch.cuda.synchronize()
+    progress('warm-up done')
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -118,6 +127,7 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = dist.max_float(time.perf_counter() - t0, dev)
+    progress('timed steps done')
     losses = eng.losses.cpu().tolist()
     rows = args.batch * dist.world * args.steps
     args.workload = workload_string(args, table, dims)
@@ -142,10 +152,13 @@ def main():
     if dist.rank == 0 and not args.no_roofline:
         if dist.world == 1:
             out.update(step_kernel_rooflines(eng, eager_step, args))
+            progress('per-kernel roofline figures done')
         out.update(standalone_dp_kernels(eng, dev))
+        progress('stand-alone DP kernels done')
 
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(eng, span, args)
+        progress('CPU baseline done')
 
     dist.barrier()
     if dist.rank == 0:

@@ -19,6 +19,16 @@
 // The wide-row kernel (one thread per (row, span), straight from global memory) stays as the path for
 // rows longer than the LDS tile.
 // ---------------------------------------------------------------------------------------------
+// One term of the conditional loss (closed form) and its gradient factor: BCE-with-logits of the raw
+// output x against the cond entry c under mask m.  One function for the three kernels that take the loss.
+__device__ __forceinline__ float act_loss_term(float xv, float c, float m, float scale, float& gval) {
+  const float ex = dpc_fast_exp(-fabsf(xv));
+  const float r = dpc_fast_rcp(1.f + ex);
+  const float sig = xv >= 0.f ? r : ex * r;
+  gval = scale * m * (sig - c);
+  return m * (fmaxf(xv, 0.f) - xv * c + dpc_fast_ln(1.f + ex));
+}
+
 struct ActFwdArgs {
   const float* x; int64_t ldx; float* y; int64_t ldy; const int32_t* spans; int nspan; int64_t B; int Dd;
   const float* en; int64_t ld_en; const uint64_t* rng; uint32_t site; float inv_tau;
@@ -53,8 +63,8 @@ __global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
         const uint32_t r = e / Dd, col = e - r * Dd;
         const int64_t b = b0 + r;
         const float xv = a.x[b * a.ldx + col];
-        const float ev = a.en ? a.en[b * a.ld_en + col] : -logf(dpc_u32_to_unit(ph.v[l]));
-        tile[e] = (xv - logf(ev)) * a.inv_tau;
+        const float ev = a.en ? a.en[b * a.ld_en + col] : dpc_exp1(ph.v[l]);
+        tile[e] = (xv - dpc_fast_ln(ev)) * a.inv_tau;
         if (LOSS) {
           const int d = a.col2d[col];
           float gval = 0.f;
@@ -62,10 +72,7 @@ __global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
             const float m = (float)a.mask[b * a.ldm + d];
             if (m != 0.f) {
               const float c = a.cond[b * a.ldc + a.col2c[col]];
-              const float ex = expf(-fabsf(xv));
-              acc += (double)(m * (fmaxf(xv, 0.f) - xv * c + log1pf(ex)));
-              const float sig = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
-              gval = a.scale * m * (sig - c);
+              acc += (double)act_loss_term(xv, c, m, a.scale, gval);
             }
           }
           if (a.dfake) a.dfake[b * a.lddf + col] = gval;
@@ -81,17 +88,17 @@ __global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
       float* tr = tile + r * Dd + off;
       if (kind == 0) {
         const float* xr = a.x + (b0 + r) * a.ldx + off;
-        for (int j = 0; j < dim; ++j) tr[j] = tanhf(xr[j]);
+        for (int j = 0; j < dim; ++j) tr[j] = dpc_fast_tanh(xr[j]);
       } else {
         float mx = -INFINITY;
         for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
         float sum = 0.f;
         for (int j = 0; j < dim; ++j) {
-          const float ev = expf(tr[j] - mx);
+          const float ev = dpc_fast_exp(tr[j] - mx);
           tr[j] = ev;
           sum += ev;
         }
-        const float inv = 1.f / sum;
+        const float inv = dpc_fast_rcp(sum);
         for (int j = 0; j < dim; ++j) tr[j] *= inv;
       }
     }
@@ -109,26 +116,47 @@ __global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
   }
 }
 
-// The same three phases with every table in LDS as well (narrow rows: Adult, T1M, T10M): a phase 0
-// brings the raw tile (and the tile's mask rows) in with independent coalesced loads - all of a thread's
-// loads in flight at once - so that phases 1 and 2 touch global memory only for stores (and for the few
-// cond-vector entries behind a set mask bit).  LDS: xs[R*Dd] raw | ts[R*Dd] | spans[3*nspan] |
-// LOSS: col2d[Dd] | col2c[Dd] | mask tile [R*nd].
-// What bounds this kernel is instruction issue (8 resident blocks per CU, ~1000 instructions per thread)
-// and the barrier wait for the slowest wave, so: rows are walked by loops instead of flat indices (a 32-bit
-// division by the runtime row length is ~30 instructions), a Philox block's four elements share one
-// division, the host picks R so that the tile's Philox blocks fill whole rounds of 256 threads, spans of up
-// to 4 columns - all of them through the reference's public wrapper - stay in registers, and the
-// conditional loss is taken per SPAN in phase 2: only the two chosen discrete columns of a row contribute
-// (mask bit set), so the transcendental path runs for ~1 lane in 64 instead of diverging every wave.
+// Narrow rows (Adult, T1M, T10M): two phases around ONE barrier, laid out for the instruction count.  Round 3's SQ
+// counters showed the three-phase form (rows staged through LDS on the way in and on the way out) VALU-bound at 166
+// instructions per element - library logf / expf / division (now the hardware units, dpc_common.h) and per-element
+// index bookkeeping.
+//   LDS     ts[R][ldT] logits (ldT = Dd rounded up to 4) | spans[3*nspan] | LOSS: col2d[Dd] | col2c[Dd] | mask [R*nd].
+//   phase 1 one thread per (row, Philox block that touches the row): a row of Dd elements starting at flat index
+//           b*Dd lies in at most nqr = (Dd+3)/4 + 1 blocks; a block on a row boundary is computed by both rows
+//           (2 in ~85), which buys a thread whose four elements share one row - no wrap-around bookkeeping.  The
+//           four raw outputs come straight from global memory (consecutive threads, consecutive addresses) while
+//           the Philox block is computed; t = (x - log E) / tau goes to LDS.
+//   phase 2 one thread per (row, span): softmax over the span's LDS values (max, exp, sum in column order, scale
+//           by 1/sum); spans of up to 4 columns - all of them through the reference's public wrapper - stay in
+//           registers; the result goes straight to y (consecutive threads hold consecutive spans: the wave's stores
+//           are contiguous).  tanh spans and the conditional loss read their raw values again (L2-hot; the loss only
+//           for the two chosen discrete columns of a row - mask bit set - so its transcendentals run for ~1 lane in
+//           64), and the loss gradient is written here as well.
+// Rows and items are found from flat indices by a float reciprocal + correction (exact below 2^16; a 32-bit division
+// by a runtime value is ~30 instructions).
+// Measured at T1M's 8192 x 335 (tools/act_bench.py, launches back to back in a graph): 20.7 -> 14.0 us, with the loss
+// 37 -> 23.5 us; a plain copy of the same bytes takes 4.7 us.  With phases switched off one at a time: reading the
+// rows into LDS alone 7.6 us, + coalesced stores 10.7 us (the load -> barrier -> store skeleton at ~20 KB in flight
+// per CU is latency-bound), Philox + logs 1.1 us, the span pass 5.5 us (12.7 us with the loss: one L2 round trip per
+// pass of its item loop).  Tried on top and not kept: raw rows and the tile's cond rows staged in LDS with span-owner
+// threads walking the rows (no global load in phase 2: 13.7 / 27-31 us), two items per thread with both items'
+// loads issued first (+-0), 16-byte staging loads with padded LDS rows (+-0).
+__device__ __forceinline__ uint32_t act_div(uint32_t x, uint32_t d, float inv_d) {
+  uint32_t q = (uint32_t)((float)x * inv_d);
+  if ((q + 1) * d <= x) ++q;
+  if (q * d > x) --q;
+  return q;
+}
+
 template <bool LOSS>
 __global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, int nd) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ double red[16];
   const uint32_t Dd = (uint32_t)a.Dd, R = (uint32_t)a.R, nspan = (uint32_t)a.nspan;
-  float* xs = tile;                       // raw tile; phase 2 turns it into the loss gradient (LOSS)
-  float* ts = tile + R * Dd;
-  int32_t* sp = reinterpret_cast<int32_t*>(ts + R * Dd);
+  const uint32_t ldT = (Dd + 3u) & ~3u;
+  const uint32_t nqr = ((Dd + 3u) >> 2) + 1u;
+  float* ts = tile;
+  int32_t* sp = reinterpret_cast<int32_t*>(ts + R * ldT);
   int32_t* c2d = sp + 3 * nspan;
   int32_t* c2c = c2d + Dd;
   int32_t* mk = c2c + Dd;
@@ -139,118 +167,103 @@ __global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, i
       c2c[i] = a.col2c[i];
     }
   }
+  const float inv_nqr = 1.0f / (float)nqr, inv_ns = 1.0f / (float)nspan;
   double acc = 0.0;
-  const float inv_dd = 1.0f / (float)Dd;
   const int64_t ntiles = (a.B + R - 1) / R;
   for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const int64_t b0 = tix * R;
     const uint32_t rows = (uint32_t)min((int64_t)R, a.B - b0);
-    const uint32_t nel = rows * Dd;
-    // ---- phase 0: raw tile (and mask rows), every load independent
     const float* __restrict__ xg = a.x + b0 * a.ldx;
-    for (uint32_t r = 0; r < rows; ++r)
-      for (uint32_t col = threadIdx.x; col < Dd; col += 256) xs[r * Dd + col] = xg[r * a.ldx + col];
     if (LOSS) {
       const int32_t* __restrict__ mg = a.mask + b0 * a.ldm;
       for (uint32_t r = 0; r < rows; ++r)
         for (uint32_t d = threadIdx.x; d < (uint32_t)nd; d += 256) mk[r * (uint32_t)nd + d] = mg[r * a.ldm + d];
     }
-    __syncthreads();
-    // ---- phase 1
-    const uint64_t f0 = (uint64_t)b0 * Dd, f1 = f0 + nel;
-    const uint64_t q0 = f0 >> 2, q1 = (f1 + 3) >> 2;
-    for (uint64_t q = q0 + threadIdx.x; q < q1; q += 256) {
-      DpcPhilox4 ph;
-      if (!a.en) ph = dpc_philox(a.rng[0], a.rng[1], a.site, q);
-      const uint64_t fq = q << 2;
-      const int lo = fq < f0 ? (int)(f0 - fq) : 0;                    // first of the four that lies inside the tile
-      uint32_t e = (uint32_t)(fq + lo - f0);
-      uint32_t r = (uint32_t)((float)e * inv_dd);                      // e / Dd, corrected: e < 2^16 here
-      if ((r + 1) * Dd <= e) ++r;
-      if (r * Dd > e) --r;
-      uint32_t col = e - r * Dd;
+    // ---- phase 1: one thread per (row, Philox block)
+    const uint32_t nit = rows * nqr;
+    for (uint32_t it = threadIdx.x; it < nit; it += 256) {
+      const uint32_t r = act_div(it, nqr, inv_nqr), j = it - r * nqr;
+      const uint64_t fr = (uint64_t)(b0 + r) * Dd;                 // flat index of the row's first element
+      const int c0 = (int)(j << 2) - (int)((uint32_t)fr & 3u);     // column of the block's first element
+      if (c0 >= (int)Dd) continue;                                 // (the row ends one block earlier)
+      const float* __restrict__ xr = xg + r * a.ldx;
+      const float* __restrict__ er = a.en ? a.en + (b0 + r) * a.ld_en : xr;
+      float xv[4], ev[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {                                // (columns clamped into the row: no branch per load)
+        const int col = min(max(c0 + l, 0), (int)Dd - 1);
+        xv[l] = xr[col];
+        ev[l] = er[col];
+      }
+      if (!a.en) {
+        const DpcPhilox4 ph = dpc_philox(a.rng[0], a.rng[1], a.site, (fr >> 2) + j);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) ev[l] = dpc_exp1(ph.v[l]);
+      }
+      float* tr = ts + r * ldT;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
-        if (l < lo || e >= nel) continue;
-        const float ev = a.en ? a.en[(b0 + r) * a.ld_en + col] : -logf(dpc_u32_to_unit(ph.v[l]));
-        ts[e] = (xs[e] - logf(ev)) * a.inv_tau;
-        ++e;
-        if (++col == Dd) { col = 0; ++r; }
+        const int col = c0 + l;
+        if (col >= 0 && col < (int)Dd) tr[col] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
       }
     }
     __syncthreads();
     // ---- phase 2: one thread per (row, span)
-    for (uint32_t r = 0; r < rows; ++r) {
-      for (uint32_t s = threadIdx.x; s < nspan; s += 256) {
-        const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
-        float* tr = ts + r * Dd + off;
-        float* xr = xs + r * Dd + off;
-        if (kind == 0) {
-          for (int j = 0; j < dim; ++j) {
-            tr[j] = tanhf(xr[j]);
-            if (LOSS) xr[j] = 0.f;
-          }
-          continue;
+    const uint32_t nitem = rows * nspan;
+    for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
+      const uint32_t r = act_div(it, nspan, inv_ns), s = it - r * nspan;
+      const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
+      const float* tr = ts + r * ldT + off;
+      const float* __restrict__ xr = xg + r * a.ldx + off;
+      float* __restrict__ yr = a.y + (b0 + r) * a.ldy + off;
+      float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + (b0 + r) * a.lddf + off : nullptr;
+      if (kind == 0) {
+        for (int j = 0; j < dim; ++j) {
+          yr[j] = dpc_fast_tanh(xr[j]);
+          if (LOSS && dr) dr[j] = 0.f;
         }
-        if (dim <= 4) {
-          float t[4];
-          float mx = -INFINITY;
+        continue;
+      }
+      if (dim <= 4) {
+        float t[4];
+        float mx = -INFINITY;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t[j] = j < dim ? tr[j] : -INFINITY;
-            mx = fmaxf(mx, t[j]);
-          }
-          float sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < dim) {
-              t[j] = expf(t[j] - mx);
-              sum += t[j];
-            }
-          }
-          const float inv = 1.f / sum;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < dim) tr[j] = t[j] * inv;
-        } else {
-          float mx = -INFINITY;
-          for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
-          float sum = 0.f;
-          for (int j = 0; j < dim; ++j) {
-            const float ev = expf(tr[j] - mx);
-            tr[j] = ev;
-            sum += ev;
-          }
-          const float inv = 1.f / sum;
-          for (int j = 0; j < dim; ++j) tr[j] *= inv;
+        for (int j = 0; j < 4; ++j) {
+          t[j] = j < dim ? tr[j] : -INFINITY;
+          mx = fmaxf(mx, t[j]);
         }
-        if (LOSS) {
-          const int d = c2d[off];                 // >= 0: a discrete column (its span is the whole column)
-          const float m = d >= 0 ? (float)mk[r * (uint32_t)nd + d] : 0.f;
-          if (m != 0.f) {
-            const float* cr = a.cond + (b0 + r) * a.ldc + c2c[off];
-            for (int j = 0; j < dim; ++j) {
-              const float xv = xr[j], c = cr[j];
-              const float ex = expf(-fabsf(xv));
-              acc += (double)(m * (fmaxf(xv, 0.f) - xv * c + log1pf(ex)));
-              const float sig = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
-              xr[j] = a.scale * m * (sig - c);
-            }
-          } else {
-            for (int j = 0; j < dim; ++j) xr[j] = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t[j] = dpc_fast_exp(t[j] - mx);            // (a slot beyond dim: 2^-inf = 0)
+          sum += t[j];
+        }
+        const float inv = dpc_fast_rcp(sum);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < dim) yr[j] = t[j] * inv;
+      } else {
+        float mx = -INFINITY;
+        for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
+        float sum = 0.f;
+        for (int j = 0; j < dim; ++j) sum += dpc_fast_exp(tr[j] - mx);
+        const float inv = dpc_fast_rcp(sum);
+        for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_exp(tr[j] - mx) * inv;
+      }
+      if (LOSS) {
+        const int d = c2d[off];                 // >= 0: a discrete column (its span is the whole column)
+        const float m = d >= 0 ? (float)mk[r * (uint32_t)nd + d] : 0.f;
+        if (m != 0.f) {
+          const float* __restrict__ cr = a.cond + (b0 + r) * a.ldc + c2c[off];
+          for (int j = 0; j < dim; ++j) {
+            float gval;
+            acc += (double)act_loss_term(xr[j], cr[j], m, a.scale, gval);
+            if (dr) dr[j] = gval;
           }
+        } else if (dr) {
+          for (int j = 0; j < dim; ++j) dr[j] = 0.f;
         }
       }
-    }
-    __syncthreads();
-    // ---- phase 3
-    float* __restrict__ yg = a.y + b0 * a.ldy;
-    for (uint32_t r = 0; r < rows; ++r)
-      for (uint32_t col = threadIdx.x; col < Dd; col += 256) yg[r * a.ldy + col] = ts[r * Dd + col];
-    if (LOSS && a.dfake) {
-      float* __restrict__ dg = a.dfake + b0 * a.lddf;
-      for (uint32_t r = 0; r < rows; ++r)
-        for (uint32_t col = threadIdx.x; col < Dd; col += 256) dg[r * a.lddf + col] = xs[r * Dd + col];
     }
     __syncthreads();
   }
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __r
     const float* xr = x + b * ldx + off;
     float* yr = y + b * ldy + off;
     if (kind == 0) {
-      for (int j = 0; j < dim; ++j) yr[j] = tanhf(xr[j]);
+      for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_tanh(xr[j]);
     } else if (dim <= 16) {
       // the span lives in registers (same operations in the same order as the general path below,
       // which keeps its intermediate values in y and pays a store -> load round trip per pass)
@@ -361,8 +374,8 @@ __global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j < dim) {
-          float e = en ? en[b * ld_en + off + j] : -logf(dpc_u32_to_unit(dc.draw((uint64_t)(b * Dd + off + j))));
-          t[j] = (xr[j] - logf(e)) * inv_tau;
+          float e = en ? en[b * ld_en + off + j] : dpc_exp1(dc.draw((uint64_t)(b * Dd + off + j)));
+          t[j] = (xr[j] - dpc_fast_ln(e)) * inv_tau;
           mx = fmaxf(mx, t[j]);
         }
       }
@@ -370,11 +383,11 @@ __global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j < dim) {
-          t[j] = expf(t[j] - mx);
+          t[j] = dpc_fast_exp(t[j] - mx);
           sum += t[j];
         }
       }
-      float inv = 1.f / sum;
+      float inv = dpc_fast_rcp(sum);
 #pragma unroll
       for (int j = 0; j < 16; ++j)
         if (j < dim) yr[j] = t[j] * inv;
@@ -382,18 +395,18 @@ __global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __r
       float mx = -INFINITY;
       for (int j = 0; j < dim; ++j) {
         float e = en ? en[b * ld_en + off + j]
-                     : -logf(dpc_u32_to_unit(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j))));
-        float t = (xr[j] - logf(e)) * inv_tau;
+                     : dpc_exp1(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j)));
+        float t = (xr[j] - dpc_fast_ln(e)) * inv_tau;
         yr[j] = t;
         mx = fmaxf(mx, t);
       }
       float sum = 0.f;
       for (int j = 0; j < dim; ++j) {
-        float e = expf(yr[j] - mx);
+        float e = dpc_fast_exp(yr[j] - mx);
         yr[j] = e;
         sum += e;
       }
-      float inv = 1.f / sum;
+      float inv = dpc_fast_rcp(sum);
       for (int j = 0; j < dim; ++j) yr[j] *= inv;
     }
   }
@@ -401,27 +414,31 @@ __global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __r
 
 static int activate_fwd_impl(ActFwdArgs a, bool loss, int nd, int n_partials, int* n_used, float tau, hipStream_t st) {
   a.inv_tau = 1.0f / tau;
-  // narrow rows: raw tile, result tile and every table in LDS (activate_fwd_small_kernel).  R: among 1..8
-  // rows (<= 24 KB of LDS) the count whose Philox blocks (R*Dd/4) fill rounds of 256 threads best
+  // narrow rows: the logits of R rows and every table in LDS (activate_fwd_small_kernel).  R: among 1..16 rows
+  // (<= 40 KB of LDS) the smallest count whose phase-1 items - R rows x the nqr Philox blocks of a row - fill rounds
+  // of 256 threads best, counting a grid beyond 2048 blocks (8 resident blocks per CU) as a quarter worse
   {
+    const int64_t ldT = (a.Dd + 3) / 4 * 4, nqr = (a.Dd + 3) / 4 + 1;
+    auto lds_of = [&](int64_t R) {
+      return ((size_t)R * ldT + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
+    };
     int64_t best = 0;
     double best_u = 0.0;
-    for (int64_t R = 1; R <= 8 && R <= a.B; ++R) {
-      const size_t lds = ((size_t)2 * R * a.Dd + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
-      if (lds > (24u << 10)) break;
-      const double blocks = (double)R * a.Dd / 4.0;
-      const double u = blocks / (256.0 * (double)dpc_cdiv((int64_t)blocks + 1, 256));
+    for (int64_t R = 1; R <= 16 && R <= a.B; ++R) {
+      const int64_t items = R * (nqr > a.nspan ? nqr : (int64_t)a.nspan);
+      if (lds_of(R) > (40u << 10) || items >= 65536) break;
+      double u = (double)(R * nqr) / (256.0 * (double)dpc_cdiv(R * nqr, 256));
+      if (dpc_cdiv(a.B, R) > 2048) u *= 0.75;
       if (u > best_u + 0.02) { best_u = u; best = R; }
     }
     if (best > 0) {
       const int64_t R = best;
-      const size_t lds = ((size_t)2 * R * a.Dd + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
       a.R = (int)R;
       const int64_t ntiles = dpc_cdiv(a.B, R);
       int64_t grid = ntiles < 8192 ? ntiles : 8192;
       if (loss && grid > n_partials) grid = n_partials;
-      if (loss) hipLaunchKernelGGL(activate_fwd_small_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, a, nd);
-      else hipLaunchKernelGGL(activate_fwd_small_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, a, nd);
+      if (loss) hipLaunchKernelGGL(activate_fwd_small_kernel<true>, dim3((unsigned)grid), dim3(256), lds_of(R), st, a, nd);
+      else hipLaunchKernelGGL(activate_fwd_small_kernel<false>, dim3((unsigned)grid), dim3(256), lds_of(R), st, a, nd);
       if (n_used) *n_used = (int)grid;
       DPC_LAUNCH_CHECK();
       return DPC_OK;
@@ -609,10 +626,7 @@ __global__ __launch_bounds__(256) void cond_loss_kernel(const float* __restrict_
       if (m != 0.f) {
         float x = fake[b * ldf + j];
         float c = cond[b * ldc + col2c[j]];
-        float e = expf(-fabsf(x));
-        acc += (double)(m * (fmaxf(x, 0.f) - x * c + log1pf(e)));
-        float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-        gval = scale * m * (sig - c);
+        acc += (double)act_loss_term(x, c, m, scale, gval);
       }
     }
     if (dfake) {

@@ -102,6 +102,21 @@ struct DpcDrawCache {
 // out (with 24 bits the largest value would round up to 1.0 and -log(-log(u)) would be +inf).
 __device__ __forceinline__ float dpc_u32_to_unit(uint32_t x) { return ((x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
+// Transcendentals of the activation path on the hardware units (v_log_f32 = log2, v_exp_f32 = 2^x, v_rcp_f32; 1 ulp
+// each): the library's logf / expf / tanhf / IEEE division are 15-40 VALU instructions apiece and made the
+// activation kernels instruction-bound (166 VALU instructions per element at T1M, SQ counters).  Every kernel that
+// draws or consumes an Exp(1) number uses THESE functions, so the draws dpc_fill exposes are the fused kernels' own.
+__device__ __forceinline__ float dpc_fast_ln(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float dpc_fast_exp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
+__device__ __forceinline__ float dpc_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// Exp(1) = -ln(u), u in (0,1) (Tensor.exponential_ inside F.gumbel_softmax, dp_cgan.py:307)
+__device__ __forceinline__ float dpc_exp1(uint32_t x) { return -dpc_fast_ln(dpc_u32_to_unit(x)); }
+// tanh(x) = 1 - 2 / (e^{2x} + 1): absolute error ~1e-7 (the outputs are compared on the tensor's scale)
+__device__ __forceinline__ float dpc_fast_tanh(float x) {
+  const float e = dpc_fast_exp(2.0f * fminf(fmaxf(x, -20.f), 20.f));
+  return 1.0f - 2.0f * dpc_fast_rcp(e + 1.0f);
+}
+
 // [0,1) with 53 bits from two draws (matches the resolution of numpy's random_sample).
 __device__ __forceinline__ double dpc_u64_to_unit(uint32_t hi, uint32_t lo) {
   uint64_t a = hi >> 5, b = lo >> 6;

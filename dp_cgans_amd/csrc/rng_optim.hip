@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void fill_kernel(T* out, int64_t ld, int64_t r
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
         if (KIND == 0) v[j] = (T)p.v[j];
-        else if (KIND == 2) v[j] = (T)(-logf(dpc_u32_to_unit(p.v[j])));
+        else if (KIND == 2) v[j] = (T)dpc_exp1(p.v[j]);
         else if (KIND == 3) v[j] = (T)dpc_u32_to_unit(p.v[j]);
         else if (KIND == 4) v[j] = (T)dpc_u64_to_unit(p.v[2 * j], p.v[2 * j + 1]);
         else v[j] = (T)(p.v[j] >> 31);

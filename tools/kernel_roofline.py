@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench import FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, source_sha  # noqa: E402
 from trace_steps import step_ends  # noqa: E402
+from pmc_reduce import rows_of  # noqa: E402
 
 
 def family(name):
@@ -166,32 +167,29 @@ def main():
             ent.update(bound='unmodelled', note='no byte model for this kernel (tools/kernel_roofline.py)')
         kernels[fam] = ent
     if a.fetch and a.write:
-        def per_kernel(path):
-            v = []
-            for r in csv.DictReader(open(path)):
-                if family(r['Kernel_Name']) == 'gemm':
-                    v.append(float(r['Counter_Value']))
-            return v
-        # every family's HBM-side traffic per launch (adam: both launches' average)
-        def by_family(path):
+        # every family's HBM-side traffic per launch (adam: both launches' average); the counter files may be the raw
+        # per-dispatch CSV or its per-kernel sums (tools/pmc_reduce.py)
+        def by_family(path, counts=None):
             acc = collections.defaultdict(lambda: [0.0, 0])
-            for r in csv.DictReader(open(path)):
-                f = family(r['Kernel_Name'])
-                acc[f][0] += float(r['Counter_Value'])
-                acc[f][1] += 1
+            for name, _, n, v in rows_of(path):
+                f = family(name)
+                acc[f][0] += v
+                acc[f][1] += n
+            if counts is not None:
+                counts.update({f: v[1] for f, v in acc.items()})
             return {f: v[0] / v[1] for f, v in acc.items()}
-        ff, fw = by_family(a.fetch), by_family(a.write)
+        launches = {}
+        ff, fw = by_family(a.fetch, launches), by_family(a.write)
         for fam, ent in kernels.items():
             key = 'adam_kernel<true>' if fam.startswith('adam_kernel_') else fam
             if fam != 'gemm' and key in ff and key in fw:
                 ent['traffic_bytes_per_launch'] = (2.0 * ff[key] + fw[key]) * 1024.0
                 if 'algorithmic_bytes_per_launch' in ent and ent['algorithmic_bytes_per_launch'] > 0:
                     ent['traffic_over_algorithmic'] = ent['traffic_bytes_per_launch'] / ent['algorithmic_bytes_per_launch']
-        gf, gw = per_kernel(a.fetch), per_kernel(a.write)
         kernels['gemm'].update(
-            traffic_bytes_per_launch=(2.0 * sum(gf) / len(gf) + sum(gw) / len(gw)) * 1024.0,
-            fetch_size_kib_avg=sum(gf) / len(gf), write_size_kib_avg=sum(gw) / len(gw), fetch_correction=2.0,
-            traffic_launches=len(gf),
+            traffic_bytes_per_launch=(2.0 * ff['gemm'] + fw['gemm']) * 1024.0,
+            fetch_size_kib_avg=ff['gemm'], write_size_kib_avg=fw['gemm'], fetch_correction=2.0,
+            traffic_launches=launches['gemm'],
             traffic_command='rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 3 --warmup 2 '
                             '--no-cpu-baseline --no-roofline --no-graph')
         kernels['gemm']['traffic_over_algorithmic'] = (kernels['gemm']['traffic_bytes_per_launch']
@@ -201,9 +199,9 @@ def main():
         # (64 per v_mfma_f32_32x32x2_f32: the sum equals flops / 64 for full tiles), GRBM_GUI_ACTIVE the busy cycles
         # summed over the 8 XCDs (MI355X_MICROARCH.md)
         acc = collections.defaultdict(float)
-        for r in csv.DictReader(open(a.mfma)):
-            if family(r['Kernel_Name']) == 'gemm':
-                acc[r['Counter_Name']] += float(r['Counter_Value'])
+        for name, counter, _, v in rows_of(a.mfma):
+            if family(name) == 'gemm':
+                acc[counter] += v
         kernels['gemm'].update(
             mfma_busy_cycles=acc['SQ_VALU_MFMA_BUSY_CYCLES'], gui_active_cycles_sum_xcd=acc['GRBM_GUI_ACTIVE'],
             mfma_util=acc['SQ_VALU_MFMA_BUSY_CYCLES'] / (acc['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0),
