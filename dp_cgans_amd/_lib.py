@@ -68,13 +68,23 @@ class _Lib(object):
         finally:
             self.log = log
 
+    # Launch-order control for the engine's side branches (engine.StepEngine._Fork): while `defer` is a list, calls are
+    # recorded there instead of issued; `after`, when set, is called with the stream argument of every issued call.
+    defer = None
+    after = None
+
     def call(self, name, *args):
+        if self.defer is not None:
+            self.defer.append((name, args))
+            return
         if self.log is not None:
             self.log.append((name, args))
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             msg = self.cdll.dpc_last_error()
             raise RuntimeError('%s failed (%d): %s' % (name, rc, msg.decode() if msg else ''))
+        if self.after is not None and args:
+            self.after(args[-1])
 
 
 _lib = None

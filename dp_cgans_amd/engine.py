@@ -351,6 +351,14 @@ class StepEngine(object):
         self.pair_part = torch.zeros(2 * 64 * 2 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self.pair_fold = torch.zeros(4 * max(self.gdim + [1]), device=d, dtype=torch.float64)
         self._open = []          # side streams with work the main stream has not joined yet
+        self._pending = []       # side branches recorded but not yet issued (_Fork)
+        # which fork sites issue their branch AFTER the main stream's next launch (_Fork; one bit per site: 0 real rows /
+        # W1 W1^T, 1 the early lane, 2-3 the discriminator's weight-gradient branches, 4 hot-id sorts, 5 the output
+        # layer's weight gradient, 6 the Residual blocks' weight gradients, 7 running statistics).  Measured one by one
+        # at T1M (0.679 ms with none): 0 -9 us, 4 -5, 6 -4, 2 -4, 3 -3, 7 -2, but 1 +56 and 5 +23 (the lane then shares
+        # a queue with the branches it should run beside); 0|4|6 together 0.664 ms, every larger set 0.664-0.667.
+        self.defer_forks = int(os.environ.get('DPCGAN_DEFER_FORKS', '0x51'), 0)
+        self._defer_ok = True    # (off while a step runs with injected draws: those bodies hold torch copies)
         self._g1_issued = False  # W1 W1^T of this discriminator update is already on its way (_draw_inputs)
         self._pair_sort = False  # _gen_forward_pair issues the hot-id sort at the end of its second lane
         self._pair_R = {}        # row chunks of the paired forwards' column reductions, per layer
@@ -566,7 +574,7 @@ class StepEngine(object):
         """Real rows that match the cond vectors of ``c`` (data_sampler.py:382-396) on a side branch."""
         B, Dd, C = self.B, self.Dd, self.C
         real = self.Xd[B:2 * B]
-        with self._fork(0):      # beside the generator forward; joined before the interpolation
+        with self._fork(0, 0):      # beside the generator forward; joined before the interpolation
             if 'real' in inj:
                 real[:, :Dd].copy_(inj['real'])
                 real_cond = inj['real_cond'] if 'real_cond' in inj else c.cond[inj['perm']]
@@ -928,18 +936,36 @@ class StepEngine(object):
 
     class _Fork(object):
         """``with eng._fork(k):`` runs the block on side stream k after everything issued so far on
-        the main stream; ``eng._join()`` makes the main stream wait for all open side streams."""
+        the main stream; ``eng._join()`` makes the main stream wait for all open side streams.
 
-        def __init__(self, eng, k):
-            self.eng, self.k = eng, k
+        Launch order (``eng.defer_forks``): the block's launches are RECORDED while the block runs and issued right
+        after the main stream's next launch (``_after_call``), behind an event taken here.  Dependencies are the same;
+        what changes is the order in which the graph capture sees the two successors of the fork point.  The HIP graph
+        runtime cuts a graph into chains by a depth-first walk along each node's FIRST successor and gives every
+        chain a hardware queue: with the branch launched first the branch inherits the main stream's chain and the
+        main stream's next kernel starts a new one - on another queue, behind a cross-queue dependency (~10 us in
+        the round-3 traces against ~0 between two kernels of one queue), at every fork of the step."""
+
+        def __init__(self, eng, k, site=0):
+            self.eng, self.k, self.site = eng, k, site
 
         def __enter__(self):
             e = self.eng
+            self.rec = None
             if not e.concurrent or not e.side or e._inline:
                 self.ctx = None
                 return e.part
             side = e.side[self.k]
-            side.wait_stream(torch.cuda.current_stream(e.dev))
+            main = torch.cuda.current_stream(e.dev)
+            L = ops.lib()
+            if (e.defer_forks >> self.site) & 1 and e._defer_ok and L.defer is None:
+                self.ev = torch.cuda.Event()
+                self.ev.record(main)
+                self.main = main.cuda_stream
+                self.rec = L.defer = []
+            else:
+                e._flush_pending()
+                side.wait_stream(main)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
             if side not in e._open:
@@ -949,10 +975,36 @@ class StepEngine(object):
         def __exit__(self, *a):
             if self.ctx is not None:
                 self.ctx.__exit__(*a)
+            if self.rec is not None:
+                e, L = self.eng, ops.lib()
+                L.defer = None
+                if a[0] is None:
+                    e._pending.append((self.main, e.side[self.k], self.ev, self.rec))
+                    L.after = e._after_call
             return False
 
-    def _fork(self, k):
-        return StepEngine._Fork(self, k)
+    def _after_call(self, stream):
+        """A launch has been issued: if it went to the stream a pending branch forked from, the branch goes now."""
+        h = getattr(stream, 'value', stream) or 0      # (c_void_p(0).value is None: the default stream)
+        if any(p[0] == h for p in self._pending):
+            self._flush_pending()
+
+    def _flush_pending(self):
+        if not self._pending:
+            return
+        L = ops.lib()
+        L.after = None
+        pending, self._pending = self._pending, []
+        for _, side, ev, rec in pending:
+            if callable(rec):           # the early lane (train_step)
+                rec(ev)
+                continue
+            side.wait_event(ev)
+            for name, args in rec:
+                L.call(name, *args)
+
+    def _fork(self, k, site=0):
+        return StepEngine._Fork(self, k, site)
 
     def _probe(self, label):
         """Critical-path probe (tuning aid, off unless DPCGAN_DELAY=<label>:<cycles> is set): a spin node of that many
@@ -967,6 +1019,7 @@ class StepEngine(object):
     def _join(self):
         if self._inline:         # issuing the early branch: it forks nothing, and the open forks belong to the main stream
             return
+        self._flush_pending()
         main = torch.cuda.current_stream(self.dev)
         for side in self._open:
             main.wait_stream(side)
@@ -1013,6 +1066,7 @@ class StepEngine(object):
         step counters itself; inside ``train_step`` it is update number ``sub`` of the step, draws
         from call sites offset by 64*sub and leaves the single end-of-step advance to the caller."""
         inj = inj or {}
+        self._defer_ok = not inj
         self._so = 0 if sub is None else 64 * sub
         self._probe('d_inputs')
         self._draw_inputs(inj, need_real=True, c=self.cd)
@@ -1023,6 +1077,7 @@ class StepEngine(object):
 
     def _d_back(self, inj, update, sub):
         """Everything of a discriminator update after its generator forward + activation."""
+        self._defer_ok = not inj
         self._so = 0 if sub is None else 64 * sub
         self._k = 0 if sub is None else sub
         n, B, M, d = self.n, self.B, self.M, self.disc
@@ -1041,7 +1096,7 @@ class StepEngine(object):
             # so neither xhat, g0 = u W1 nor v0 (each [n, K0]) is formed, and the K0-wide products
             # shrink from 3n to 2n rows (forward, weight gradient) or disappear (g0, v1).
             if not self._g1_issued:
-                with self._fork(0):
+                with self._fork(0, 0):
                     self._mm(W1, W1, self.G1, trans_b=True, beta=1.0)
             self._g1_issued = False
             self._disc_forward_stacked(inj)
@@ -1102,7 +1157,7 @@ class StepEngine(object):
             # sums and the cond columns' sorted row sums on a branch beside it, then the one product that depends on
             # the group (P1 W1 into dW1).  Before: three graph branches of 1 + 2 + (M-1) launches whose fixed costs
             # and fork / join pairs the step paid per branch (phase 78 -> ~60 us in the T1M trace).
-            with self._fork(1) as part:
+            with self._fork(1, 2) as part:
                 probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
                 probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
                 probs.append((self.ones_col, w_last[0:2 * n], d.G('seq.%d.bias' % (3 * M))))
@@ -1113,7 +1168,7 @@ class StepEngine(object):
                                      rowscale=kscale[0:2 * n] if kscale is not None else None)
                 self._flush_head()
             u = self.Dl[0][gp_rows]
-            with self._fork(0):
+            with self._fork(0, 3):
                 # the penalty's share of dW1, (u^T diag(f c) u) W1: two small dependent products beside the group (the
                 # d0 x d0 one over n rows has 16 tiles - cut along K so that it brings 128 blocks, not 16); it ADDS to
                 # dW1 while the group's first product does: atomics on both sides
@@ -1132,7 +1187,7 @@ class StepEngine(object):
             self._join()
             self._d_grads_tail(update, inj, sub)
             return
-        with self._fork(1) as part:
+        with self._fork(1, 2) as part:
             probs = [(self.Dl[i][0:2 * n], w_bias, d.G('seq.%d.bias' % (3 * i))) for i in range(M)]
             probs.append((self.H[M - 1], w_last, d.G('seq.%d.weight' % (3 * M)).view(-1)))
             probs.append((self.ones_col, w_last[0:2 * n], d.G('seq.%d.bias' % (3 * M))))
@@ -1154,7 +1209,7 @@ class StepEngine(object):
             # penalty part (u^T diag(f c) u) W1 beside the fake and real rows' product: both ADD into the zeroed
             # gradient (the penalty part with atomics too - the two run at the same time)
             u = self.Dl[0][gp_rows]
-            with self._fork(0):
+            with self._fork(0, 3):
                 self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale)
                 self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0, atomic=not self.deterministic)
             ks2 = kscale[0:2 * n] if kscale is not None else None
@@ -1248,6 +1303,7 @@ class StepEngine(object):
         """The part of a generator update that reads nothing a discriminator update writes: zeroed
         gradient buffer, z / cond inputs, generator forward, output activation."""
         self._so = 0 if sub is None else 64 * sub
+        self._defer_ok = not inj
         c = self.cg
         # (the pool fill - one for all weight gradients: their split-K products then accumulate with beta = 1 - rides
         # in the launch that draws the inputs)
@@ -1259,7 +1315,7 @@ class StepEngine(object):
                 # and the lane is as long as the discriminator update it runs beside - _g_back issues it instead
                 self._sort_pending = True
             else:
-                with self._fork(1):      # beside the forward; the backward's weight gradients read it
+                with self._fork(1, 4):      # beside the forward; the backward's weight gradients read it
                     ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._gen_forward(c, running=running)
         self._activate_loss(inj, c)
@@ -1278,13 +1334,14 @@ class StepEngine(object):
                                                     site=ops.SITE_GUMBEL + self._so, batch_total=self.gB)
 
     def _g_back(self, inj, update, sub):
+        self._defer_ok = not inj
         self._so = 0 if sub is None else 64 * sub
         self._k = 0
         self._last = c = self.cg
         n, B, M, L, d, g = self.n, self.B, self.M, self.L, self.disc, self.gen
         if getattr(self, '_sort_pending', False):
             self._sort_pending = False
-            with self._fork(1):          # joined below, in front of the first weight-gradient branch
+            with self._fork(1, 4):          # joined below, in front of the first weight-gradient branch
                 ops.hot_sort(c.sel, self.C, c.order, c.sid, c.n_items)
         self._disc_forward(n, inj, y=self.y_g, rowscale=self.rowscale_g, X3=c.X3, sel=c.sel if self.sparse_d else None)
         self._loss_dirty[1] = True
@@ -1323,7 +1380,7 @@ class StepEngine(object):
         # backward launches and the output layer's column sum on this branch, so that no column-sum launch is left in
         # front of the Adam step - 0.693 -> 0.701 ms: 256 row chunks adding to the same 256 addresses serialise in L2
         # and lengthen the two BatchNorm-backward launches of the critical chain by more than the launch they save)
-        with self._fork(0):
+        with self._fork(0, 5):
             self._probe('g_out_dweight_branch')
             self._gen_dweight(c, L, self.dfake)
             self._flush_head()
@@ -1350,11 +1407,11 @@ class StepEngine(object):
             if l == 0:
                 # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
                 # bias gradients of every layer (one launch pair) while the product runs beside it
-                with self._fork((L - l) % 2):
+                with self._fork((L - l) % 2, 6):
                     self._gen_dweight(c, l, self.dZ[l], what=1)
                 self._gen_dweight(c, l, self.dZ[l], what=2)
             else:
-                with self._fork((L - l) % 2):                   # after the chain's product, as above
+                with self._fork((L - l) % 2, 6):                   # after the chain's product, as above
                     self._gen_dweight(c, l, self.dZ[l])
         self._gen_bias_grads(self.part)
         self._join()
@@ -1411,7 +1468,7 @@ class StepEngine(object):
                 self._draw_inputs({}, need_real=False, c=self.cg, zero=self._gen_gx)
                 self._pair_sort = False
                 if self.sparse_cond:
-                    with self._fork(1):      # joined by the first collective; the generator backward reads it
+                    with self._fork(1, 4):      # joined by the first collective; the generator backward reads it
                         ops.hot_sort(self.cg.sel, self.C, self.cg.order, self.cg.sid, self.cg.n_items)
             self._gen_forward_pair(self.cd, self.cg, 64 * last, 64 * d_steps)
             self._d_back({}, True, last)
@@ -1425,15 +1482,27 @@ class StepEngine(object):
                 # (the penalty chain, the clip factors, the weight gradients: many small kernels, while
                 # beside the big first-layer GEMMs it would only take CUs from them);
                 # its BatchNorm running-statistics update waits for its turn (_bn_running below)
-                def issue():
+                def issue(ev=None):
                     # forked where the discriminator forward ends.  (How the graph runtime maps branches
                     # to its 4 hardware queues depends on the capture order: issued a few kernels later
                     # the branch lands behind the bias-gradient reductions and overlaps nothing; forked
                     # before the first-layer GEMM it takes CUs from it.  Measured: 1.124 ms here,
                     # 1.137 / 1.219 ms for those two.)
                     self._early_hook = None
+                    if ev is None and (self.defer_forks >> 1) & 1:
+                        # (launch order as for every fork: the lane is issued after the main stream's next launch,
+                        # behind an event taken here - see _Fork)
+                        main = torch.cuda.current_stream(self.dev)
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        self._pending.append((main.cuda_stream, None, ev, issue))
+                        ops.lib().after = self._after_call
+                        return
                     so = self._so
-                    self.early.wait_stream(torch.cuda.current_stream(self.dev))
+                    if ev is None:
+                        self.early.wait_stream(torch.cuda.current_stream(self.dev))
+                    else:
+                        self.early.wait_event(ev)
                     self._inline = True
                     try:
                         with torch.cuda.stream(self.early):
@@ -1446,8 +1515,9 @@ class StepEngine(object):
                 self._early_hook = issue
             self.d_step(sub=k)
         if overlap:
+            self._flush_pending()
             torch.cuda.current_stream(self.dev).wait_stream(self.early)
-            with self._fork(1):
+            with self._fork(1, 7):
                 self._bn_running(self.cg)
             self._g_back({}, True, d_steps)
         else:
