@@ -5,20 +5,6 @@
 // the gradient) per element plus the cond/mask rows for the loss.
 #include "dpc_common.h"
 
-// ---------------------------------------------------------------------------------------------
-// Tiled form (rows short enough for R >= 1 of them to sit in LDS): a block owns R consecutive rows.
-//   phase 1  one thread per Philox block of 4 consecutive flat indices b*Dd + col: reads the 4 raw
-//            outputs, draws / reads their Exp(1) numbers and leaves t = (x - log E) / tau in LDS - every
-//            Philox block is computed exactly once, and consecutive threads touch consecutive addresses.
-//            The conditional loss (dpc_activate_cond_loss_fwd) is taken here too: it needs exactly the
-//            raw outputs this phase has in registers.
-//   phase 2  one thread per (row, span): softmax over the span's LDS values (max, exp, sum in column
-//            order, scale by 1/sum - the arithmetic and order of the wide-row kernel); tanh spans read
-//            their raw value again (L2-hot, one element per continuous column).
-//   phase 3  the tile goes out with coalesced stores.
-// The wide-row kernel (one thread per (row, span), straight from global memory) stays as the path for
-// rows longer than the LDS tile.
-// ---------------------------------------------------------------------------------------------
 // One term of the conditional loss (closed form) and its gradient factor: BCE-with-logits of the raw
 // output x against the cond entry c under mask m.  One function for the three kernels that take the loss.
 __device__ __forceinline__ float act_loss_term(float xv, float c, float m, float scale, float& gval) {
@@ -37,84 +23,6 @@ struct ActFwdArgs {
   const float* cond; int64_t ldc; const int32_t* mask; int64_t ldm; const int32_t* col2d; const int32_t* col2c;
   float scale; float* dfake; int64_t lddf; double* partials;
 };
-
-template <bool LOSS>
-__global__ __launch_bounds__(256) void activate_fwd_tiled_kernel(ActFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];       // [R][Dd]
-  __shared__ double red[16];
-  const uint32_t Dd = (uint32_t)a.Dd;
-  double acc = 0.0;
-  const int64_t ntiles = (a.B + a.R - 1) / a.R;
-  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
-    const int64_t b0 = tix * a.R;
-    const uint32_t rows = (uint32_t)min((int64_t)a.R, a.B - b0);
-    const uint32_t nel = rows * Dd;
-    // ---- phase 1
-    const uint64_t f0 = (uint64_t)b0 * Dd, f1 = f0 + nel;
-    const uint64_t q0 = f0 >> 2, q1 = (f1 + 3) >> 2;
-    for (uint64_t q = q0 + threadIdx.x; q < q1; q += 256) {
-      DpcPhilox4 ph;
-      if (!a.en) ph = dpc_philox(a.rng[0], a.rng[1], a.site, q);
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const uint64_t f = (q << 2) + l;
-        if (f < f0 || f >= f1) continue;
-        const uint32_t e = (uint32_t)(f - f0);
-        const uint32_t r = e / Dd, col = e - r * Dd;
-        const int64_t b = b0 + r;
-        const float xv = a.x[b * a.ldx + col];
-        const float ev = a.en ? a.en[b * a.ld_en + col] : dpc_exp1(ph.v[l]);
-        tile[e] = (xv - dpc_fast_ln(ev)) * a.inv_tau;
-        if (LOSS) {
-          const int d = a.col2d[col];
-          float gval = 0.f;
-          if (d >= 0) {
-            const float m = (float)a.mask[b * a.ldm + d];
-            if (m != 0.f) {
-              const float c = a.cond[b * a.ldc + a.col2c[col]];
-              acc += (double)act_loss_term(xv, c, m, a.scale, gval);
-            }
-          }
-          if (a.dfake) a.dfake[b * a.lddf + col] = gval;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- phase 2
-    const uint32_t nitem = rows * (uint32_t)a.nspan;
-    for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
-      const uint32_t r = it / (uint32_t)a.nspan, s = it - r * (uint32_t)a.nspan;
-      const int off = a.spans[3 * s], dim = a.spans[3 * s + 1], kind = a.spans[3 * s + 2];
-      float* tr = tile + r * Dd + off;
-      if (kind == 0) {
-        const float* xr = a.x + (b0 + r) * a.ldx + off;
-        for (int j = 0; j < dim; ++j) tr[j] = dpc_fast_tanh(xr[j]);
-      } else {
-        float mx = -INFINITY;
-        for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
-        float sum = 0.f;
-        for (int j = 0; j < dim; ++j) {
-          const float ev = dpc_fast_exp(tr[j] - mx);
-          tr[j] = ev;
-          sum += ev;
-        }
-        const float inv = dpc_fast_rcp(sum);
-        for (int j = 0; j < dim; ++j) tr[j] *= inv;
-      }
-    }
-    __syncthreads();
-    // ---- phase 3
-    for (uint32_t e = threadIdx.x; e < nel; e += 256) {
-      const uint32_t r = e / Dd, col = e - r * Dd;
-      a.y[(b0 + r) * a.ldy + col] = tile[e];
-    }
-    __syncthreads();
-  }
-  if (LOSS && a.partials) {
-    const double tot = dpc_block_sum(acc, red);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
-  }
-}
 
 // Narrow rows (Adult, T1M, T10M): two phases around ONE barrier, laid out for the instruction count.  Round 3's SQ
 // counters showed the three-phase form (rows staged through LDS on the way in and on the way out) VALU-bound at 166
@@ -347,68 +255,182 @@ __global__ __launch_bounds__(256) void activate_bwd_tiled_kernel(ActBwdArgs a, i
 }
 
 // span table rows: (offset, dim, kind) kind 0 = tanh, 1 = gumbel-softmax
-// IT: index type of the flattened (row, span) loop; uint32_t whenever it fits (a 64-bit division per
-// thread is ~100 instructions, which showed in a kernel that does ~15 elements per row and span)
-template <typename IT>
-__global__ __launch_bounds__(256) void activate_fwd_wide_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
-                                                           int64_t ldy, const int32_t* __restrict__ spans, int nspan,
-                                                           int64_t B, int Dd, const float* __restrict__ en, int64_t ld_en,
-                                                           const uint64_t* rng, uint32_t site, float inv_tau) {
-  const IT total = (IT)B * (IT)nspan, stride = (IT)gridDim.x * blockDim.x;
-  for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const IT bq = idx / (IT)nspan;
-    const int64_t b = (int64_t)bq;
-    int s = (int)(idx - bq * (IT)nspan);
-    int off = spans[3 * s], dim = spans[3 * s + 1], kind = spans[3 * s + 2];
-    const float* xr = x + b * ldx + off;
-    float* yr = y + b * ldy + off;
-    if (kind == 0) {
-      for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_tanh(xr[j]);
-    } else if (dim <= 16) {
-      // the span lives in registers (same operations in the same order as the general path below,
-      // which keeps its intermediate values in y and pays a store -> load round trip per pass)
-      float t[16];
-      float mx = -INFINITY;
-      const uint64_t zero2[2] = {0, 0};
-      DpcDrawCache dc(en ? zero2 : rng, site);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j < dim) {
-          float e = en ? en[b * ld_en + off + j] : dpc_exp1(dc.draw((uint64_t)(b * Dd + off + j)));
-          t[j] = (xr[j] - dpc_fast_ln(e)) * inv_tau;
-          mx = fmaxf(mx, t[j]);
-        }
-      }
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j < dim) {
-          t[j] = dpc_fast_exp(t[j] - mx);
-          sum += t[j];
-        }
-      }
-      float inv = dpc_fast_rcp(sum);
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (j < dim) yr[j] = t[j] * inv;
-    } else {
-      float mx = -INFINITY;
-      for (int j = 0; j < dim; ++j) {
-        float e = en ? en[b * ld_en + off + j]
-                     : dpc_exp1(dpc_draw_u32(rng, site, (uint64_t)(b * Dd + off + j)));
-        float t = (xr[j] - dpc_fast_ln(e)) * inv_tau;
-        yr[j] = t;
-        mx = fmaxf(mx, t);
-      }
-      float sum = 0.f;
-      for (int j = 0; j < dim; ++j) {
-        float e = dpc_fast_exp(yr[j] - mx);
-        yr[j] = e;
-        sum += e;
-      }
-      float inv = dpc_fast_rcp(sum);
-      for (int j = 0; j < dim; ++j) yr[j] *= inv;
+// One (row, span) straight from global memory: the path for spans that do not fit an LDS tile.  The span's
+// intermediate values live in y (a store -> load round trip per pass), its Philox blocks are recomputed per element
+// group (DpcDrawCache).
+template <bool LOSS>
+__device__ __forceinline__ void act_span_direct(const ActFwdArgs& a, int64_t b, int off, int dim, int kind, double& acc) {
+  const float* __restrict__ xr = a.x + b * a.ldx + off;
+  float* __restrict__ yr = a.y + b * a.ldy + off;
+  float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + b * a.lddf + off : nullptr;
+  if (kind == 0) {
+    for (int j = 0; j < dim; ++j) {
+      yr[j] = dpc_fast_tanh(xr[j]);
+      if (dr) dr[j] = 0.f;
     }
+    return;
+  }
+  const uint64_t zero2[2] = {0, 0};
+  DpcDrawCache dc(a.en ? zero2 : a.rng, a.site);
+  float mx = -INFINITY;
+  for (int j = 0; j < dim; ++j) {
+    const float e = a.en ? a.en[b * a.ld_en + off + j] : dpc_exp1(dc.draw((uint64_t)(b * a.Dd + off + j)));
+    const float t = (xr[j] - dpc_fast_ln(e)) * a.inv_tau;
+    yr[j] = t;
+    mx = fmaxf(mx, t);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < dim; ++j) {
+    const float e = dpc_fast_exp(yr[j] - mx);
+    yr[j] = e;
+    sum += e;
+  }
+  const float inv = dpc_fast_rcp(sum);
+  for (int j = 0; j < dim; ++j) yr[j] *= inv;
+  if (LOSS) {
+    const int d = a.col2d[off];
+    const float m = d >= 0 ? (float)a.mask[b * a.ldm + d] : 0.f;
+    if (m != 0.f) {
+      const float* __restrict__ cr = a.cond + b * a.ldc + a.col2c[off];
+      for (int j = 0; j < dim; ++j) {
+        float gval;
+        acc += (double)act_loss_term(xr[j], cr[j], m, a.scale, gval);
+        if (dr) dr[j] = gval;
+      }
+    } else if (dr) {
+      for (int j = 0; j < dim; ++j) dr[j] = 0.f;
+    }
+  }
+}
+
+// Wide rows (TWIDE: 19 000 columns in 9 800 spans - a row does not fit the narrow kernel's LDS budget, and the
+// one-row-per-block tile that round 2 used for it ran at 0.12 of the HBM roofline: 80 KB of LDS per block, 38 serial
+// span passes per row).  Same two phases as the narrow kernel, per WORK ITEM = (tile of R rows) x (chunk of ACT_CHUNK
+// consecutive spans): the chunk's columns [cA, cB) are contiguous, phase 1 walks the Philox blocks that cover them
+// in each row (the draw of flat index b*Dd + col does not care how rows are cut), phase 2 holds one span per thread
+// and row.  Chunks are the fast index: neighbouring blocks work on neighbouring columns of the same rows.  A chunk
+// whose R rows exceed the LDS tile (spans hundreds of columns wide) takes its spans straight from global memory
+// (act_span_direct) - always correct, fast for the tables the reference's wrapper produces (2-column spans).
+constexpr int ACT_CHUNK = 256;
+
+template <bool LOSS>
+__global__ __launch_bounds__(256) void activate_fwd_chunk_kernel(ActFwdArgs a, int nd, uint32_t lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ double red[16];
+  __shared__ int32_t sp[3 * ACT_CHUNK];
+  const uint32_t Dd = (uint32_t)a.Dd, R = (uint32_t)a.R, nspan = (uint32_t)a.nspan;
+  const uint32_t nchunk = (nspan + ACT_CHUNK - 1) / ACT_CHUNK;
+  const int64_t ntiles = (a.B + R - 1) / R, nwork = ntiles * nchunk;
+  float* ts = tile;
+  double acc = 0.0;
+  for (int64_t wix = blockIdx.x; wix < nwork; wix += gridDim.x) {
+    const int64_t tix = wix / nchunk;
+    const uint32_t s0 = (uint32_t)(wix - tix * nchunk) * ACT_CHUNK, ns = min((uint32_t)ACT_CHUNK, nspan - s0);
+    for (uint32_t i = threadIdx.x; i < 3 * ns; i += 256) sp[i] = a.spans[3 * s0 + i];
+    __syncthreads();
+    const uint32_t cA = (uint32_t)sp[0], w = (uint32_t)(sp[3 * (ns - 1)] + sp[3 * (ns - 1) + 1]) - cA;
+    const int64_t b0 = tix * R;
+    const uint32_t rows = (uint32_t)min((int64_t)R, a.B - b0);
+    const uint32_t nitem = rows * ns;
+    const float inv_ns = 1.0f / (float)ns;
+    if ((uint64_t)R * w <= lds_floats && w < 32768u) {
+      // ---- phase 1: one thread per (row, Philox block that touches the chunk's columns of the row)
+      const uint32_t nqr = ((w + 3u) >> 2) + 1u, nit = rows * nqr;
+      const float inv_nqr = 1.0f / (float)nqr;
+      for (uint32_t it = threadIdx.x; it < nit; it += 256) {
+        const uint32_t r = act_div(it, nqr, inv_nqr), j = it - r * nqr;
+        const uint64_t fr = (uint64_t)(b0 + r) * Dd + cA;            // flat index of the chunk's first element in the row
+        const int c0 = (int)(j << 2) - (int)((uint32_t)fr & 3u);     // chunk-relative column of the block's first element
+        if (c0 >= (int)w) continue;
+        const float* __restrict__ xr = a.x + (b0 + r) * a.ldx + cA;
+        const float* __restrict__ er = a.en ? a.en + (b0 + r) * a.ld_en + cA : xr;
+        float xv[4], ev[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const int col = min(max(c0 + l, 0), (int)w - 1);
+          xv[l] = xr[col];
+          ev[l] = er[col];
+        }
+        if (!a.en) {
+          const DpcPhilox4 ph = dpc_philox(a.rng[0], a.rng[1], a.site, (fr >> 2) + j);
+#pragma unroll
+          for (int l = 0; l < 4; ++l) ev[l] = dpc_exp1(ph.v[l]);
+        }
+        float* tr = ts + r * w;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const int col = c0 + l;
+          if (col >= 0 && col < (int)w) tr[col] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
+        }
+      }
+      __syncthreads();
+      // ---- phase 2: one thread per (row, span of the chunk)
+      for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
+        const uint32_t r = act_div(it, ns, inv_ns), s = it - r * ns;
+        const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
+        const float* tr = ts + r * w + ((uint32_t)off - cA);
+        const float* __restrict__ xr = a.x + (b0 + r) * a.ldx + off;
+        float* __restrict__ yr = a.y + (b0 + r) * a.ldy + off;
+        float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + (b0 + r) * a.lddf + off : nullptr;
+        if (kind == 0) {
+          for (int j = 0; j < dim; ++j) {
+            yr[j] = dpc_fast_tanh(xr[j]);
+            if (LOSS && dr) dr[j] = 0.f;
+          }
+          continue;
+        }
+        if (dim <= 4) {
+          float t[4];
+          float mx = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[j] = j < dim ? tr[j] : -INFINITY;
+            mx = fmaxf(mx, t[j]);
+          }
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[j] = dpc_fast_exp(t[j] - mx);
+            sum += t[j];
+          }
+          const float inv = dpc_fast_rcp(sum);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < dim) yr[j] = t[j] * inv;
+        } else {
+          float mx = -INFINITY;
+          for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
+          float sum = 0.f;
+          for (int j = 0; j < dim; ++j) sum += dpc_fast_exp(tr[j] - mx);
+          const float inv = dpc_fast_rcp(sum);
+          for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_exp(tr[j] - mx) * inv;
+        }
+        if (LOSS) {
+          const int d = a.col2d[off];
+          const float m = d >= 0 ? (float)a.mask[(b0 + r) * a.ldm + d] : 0.f;
+          if (m != 0.f) {
+            const float* __restrict__ cr = a.cond + (b0 + r) * a.ldc + a.col2c[off];
+            for (int j = 0; j < dim; ++j) {
+              float gval;
+              acc += (double)act_loss_term(xr[j], cr[j], m, a.scale, gval);
+              if (dr) dr[j] = gval;
+            }
+          } else if (dr) {
+            for (int j = 0; j < dim; ++j) dr[j] = 0.f;
+          }
+        }
+      }
+    } else {
+      for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
+        const uint32_t r = act_div(it, ns, inv_ns), s = it - r * ns;
+        act_span_direct<LOSS>(a, b0 + r, sp[3 * s], sp[3 * s + 1], sp[3 * s + 2], acc);
+      }
+    }
+    __syncthreads();
+  }
+  if (LOSS && a.partials) {
+    const double tot = dpc_block_sum(acc, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = tot;
   }
 }
 
@@ -444,25 +466,23 @@ static int activate_fwd_impl(ActFwdArgs a, bool loss, int nd, int n_partials, in
       return DPC_OK;
     }
   }
-  a.R = act_tile_rows(a.Dd, a.B, 1);
-  DPC_CHECK_ARG(a.R > 0 || !loss, "activate_cond_loss_fwd: rows beyond 32768 columns do not fit the LDS tile");
-  if (a.R > 0) {
-    const int64_t ntiles = dpc_cdiv(a.B, a.R);
-    int64_t grid = ntiles < 4096 ? ntiles : 4096;
+  // wide rows: work items of R rows x ACT_CHUNK spans (activate_fwd_chunk_kernel).  LDS for R rows of the average
+  // chunk width and half as much again, at most 48 KB (asking for 48 KB always left 3 blocks per CU); a chunk that
+  // still does not fit goes the direct way, in the kernel
+  {
+    const int64_t nchunk = dpc_cdiv((int64_t)a.nspan, ACT_CHUNK);
+    const int64_t guess = (a.Dd / nchunk) * 3 / 2 + 4;
+    int64_t R = 12288 / guess;
+    R = R < 1 ? 1 : (R > 8 ? 8 : R);                   // (TWIDE, 12 steps of d_steps 10: R = 1 / 2 / 4 / 8 -> 91.4 / 89.5 / 88.6 / 88.4 ms)
+    if (R > a.B) R = a.B;
+    const uint32_t lds_floats = (uint32_t)(R * guess < 12288 ? R * guess : 12288);
+    a.R = (int)R;
+    const int64_t nwork = dpc_cdiv(a.B, R) * nchunk;
+    int64_t grid = nwork < 65536 ? nwork : 65536;
     if (loss && grid > n_partials) grid = n_partials;
-    const size_t lds = (size_t)a.R * a.Dd * sizeof(float);
-    const void* fn = loss ? (const void*)activate_fwd_tiled_kernel<true> : (const void*)activate_fwd_tiled_kernel<false>;
-    int rc = act_set_lds(fn, lds);
-    if (rc != DPC_OK) return rc;
-    if (loss) hipLaunchKernelGGL(activate_fwd_tiled_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(activate_fwd_tiled_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, a);
+    if (loss) hipLaunchKernelGGL(activate_fwd_chunk_kernel<true>, dim3((unsigned)grid), dim3(256), lds_floats * 4, st, a, nd, lds_floats);
+    else hipLaunchKernelGGL(activate_fwd_chunk_kernel<false>, dim3((unsigned)grid), dim3(256), lds_floats * 4, st, a, nd, lds_floats);
     if (n_used) *n_used = (int)grid;
-  } else if (a.B * a.nspan < (1LL << 31)) {
-    hipLaunchKernelGGL(activate_fwd_wide_kernel<uint32_t>, dim3(dpc_grid(a.B * a.nspan, 256)), dim3(256), 0, st, a.x, a.ldx, a.y,
-                       a.ldy, a.spans, a.nspan, a.B, a.Dd, a.en, a.ld_en, a.rng, a.site, a.inv_tau);
-  } else {
-    hipLaunchKernelGGL(activate_fwd_wide_kernel<int64_t>, dim3(dpc_grid(a.B * a.nspan, 256)), dim3(256), 0, st, a.x, a.ldx, a.y,
-                       a.ldy, a.spans, a.nspan, a.B, a.Dd, a.en, a.ld_en, a.rng, a.site, a.inv_tau);
   }
   DPC_LAUNCH_CHECK();
   return DPC_OK;

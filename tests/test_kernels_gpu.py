@@ -569,6 +569,30 @@ def test_activation_kernels_on_long_rows(ops, Dd_target):
     dx = torch.zeros(B, Dd, device=dev())
     ops.apply_activate_bwd(yo.detach().to(dev()), dy.to(dev()), dx, spans)
     close(dx, gref, what='backward')
+    # activation + conditional loss in one pass over the same wide rows == the two kernels (chunks that fit the LDS
+    # tile and chunks that go straight from global memory both take the loss)
+    col2d, col2c = (t.to(dev()) for t in col_maps(span_info))
+    cols = onets.discrete_columns(span_info)
+    nd, C = len(cols), sum(k for _, _, k in cols)
+    g = torch.Generator().manual_seed(3)
+    cond = torch.zeros(B, C)
+    mask = torch.zeros(B, nd, dtype=torch.int32)
+    for b in range(B):
+        for d in torch.randperm(nd, generator=g)[:2].tolist():
+            mask[b, d] = 1
+            cond[b, cols[d][1] + int(torch.randint(cols[d][2], (1,), generator=g))] = 1.0
+    cond, mask = cond.to(dev()), mask.to(dev())
+    part0 = torch.zeros(4096, dtype=torch.float64, device=dev())
+    part1 = torch.zeros(4096, dtype=torch.float64, device=dev())
+    d0 = torch.full((B, Dd), float('nan'), device=dev())
+    d1 = torch.full((B, Dd), float('nan'), device=dev())
+    loss0 = torch.zeros(1, device=dev())
+    ops.cond_loss(x.to(dev()), cond, mask, col2d, col2c, nd, loss0, d0, part0)
+    y1 = torch.empty(B, Dd, device=dev())
+    n = ops.activate_cond_loss_fwd(x.to(dev()), y1, spans, cond, mask, col2d, col2c, nd, d1, part1, exp_noise=e)
+    assert torch.equal(y1, yb)
+    close(d1, d0, what='loss gradient', rtol=1e-6)
+    close([float(part1[:n].sum()) * 2.0 / (B * nd)], [float(loss0)], what='ce', rtol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------
