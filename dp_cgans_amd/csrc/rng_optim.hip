@@ -176,6 +176,12 @@ __device__ __forceinline__ float adam_one(const AdamArgs& a, int64_t i, float g,
   return p;
 }
 
+// (Measured in round 3 at config 5's first Linear - 76 M parameters, half of them in cond slices - tools/adam_bench.py:
+// flat pass alone 393 us = 5.4 TB/s; slices without addend and copy 531 us, + addend 601, + copy 556, all 648 us =
+// 3.75 TB/s.  64 x 64 tiles (256-byte runs on both sides, four rows per thread in flight) changed nothing: 648 us.
+// The strided tile walk itself is what costs; the step never READS W1's cond columns in the [d0][K0] layout
+// (forward and weight gradient go through W1cT / dW1cT), so the way out is to make the transposed copy the master of
+// those parameters and their moments and update it flat - DESIGN.md section 10.)
 // A 32 x 32 tile of a cond slice: the transposed gradient addend comes in through LDS, the elements take the same
 // update as the flat blocks give (same flat index for the segment lookup and the noise draw), and the updated
 // parameters leave through LDS into the transposed copy.  256 threads, four elements each per phase, every global

@@ -41,6 +41,12 @@ us = timed(lambda: ops.adam_step_slices(p, g, m, v, 2e-4, 1e-6, [(W1, row, Dd)],
 by = 28.0 * n + 8.0 * pac * C * rows
 print('with the cond slices:      %8.1f us  %6.0f GB/s (%.2f GB)' % (us, by / us / 1e3, by / 1e9))
 
+for what, gt_on, pt_on in (('slices, no addend, no copy', 0, 0), ('slices, addend only', 1, 0), ('slices, copy only', 0, 1)):
+    sl2 = [(W, c0, nc, a if gt_on else None, b if pt_on else None) for W, c0, nc, a, b in sl]
+    us = timed(lambda: ops.adam_step_slices(p, g, m, v, 2e-4, 1e-6, [(W1, row, Dd)], sl2, **kw))
+    by = 28.0 * n + 4.0 * (gt_on + pt_on) * pac * C * rows
+    print('%-26s %8.1f us  %6.0f GB/s' % (what + ':', us, by / us / 1e3))
+
 # ---- the T1M discriminator's size (1.32 M parameters: cache-resident, latency-bound): a chain of 50 launches in one graph
 del p, g, m, v, gT, pT, W1, sl
 rows, pac, Dd, C = 256, 8, 335, 276
