@@ -24,7 +24,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_MFMA" -o pmc -- python3 bench.py "$@" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > "$out/pmc_MFMA.json.log" 2> "$out/pmc_MFMA.err"
 python3 tools/pmc_reduce.py "$out/pmc_MFMA/pmc_counter_collection.csv"
-timeout -k 10 400 python bench.py "$@" > "$out/bench_plain.json.log" 2> "$out/bench_plain.err"
+# (the CPU baseline is config 3's: one oracle step at the wide configs takes minutes)
+nocpu=""; [ "$name" != "T1M" ] && nocpu="--no-cpu-baseline"
+timeout -k 10 400 python bench.py "$@" $nocpu > "$out/bench_plain.json.log" 2> "$out/bench_plain.err"
 # the full traces stay in gpurun_out/ (tens of MB); what is judged is cut down here so that it fits the 64 MiB that travel back
 dsteps=$(python3 -c "import json,sys; print(json.loads([l for l in open('$out/bench_under_rocprof.json.log') if l.startswith('{')][-1])['config']['d_steps'])")
 python3 tools/step_timeline.py "$out/trace/bench_kernel_trace.csv" 8 "$dsteps" > "$out/step_timeline.txt"
