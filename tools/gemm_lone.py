@@ -1,5 +1,7 @@
 """A LONE 64x64 block walking a long K (one wave per SIMD on one CU, nothing else on the chip): the run the SQ
-counters of the K loop are collected on (rocprofv3 --pmc ..., see tools/profile_gemm_loop.sh)."""
+counters of the K loop are collected on:
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 tools/gemm_lone.py 64 64 16384
+(a counter pass of its own: no trace domain beside --pmc)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

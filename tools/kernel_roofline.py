@@ -67,9 +67,10 @@ def algorithmic_bytes_per_step(c):
     act_f, act_t, act_b = 8.0 * B * Dd, 12.0 * B * Dd, 16.0 * B * Dd
     m = {
         # raw output in, activated out (the discriminator updates' fake rows); + the cond-loss gradient written; backward
-        'activate_fwd_small_kernel<false>': ds * act_f, 'activate_fwd_tiled_kernel<false>': ds * act_f,
-        'activate_fwd_wide_kernel<false>': ds * act_f,
-        'activate_fwd_small_kernel<true>': act_t, 'activate_fwd_tiled_kernel<true>': act_t, 'activate_fwd_wide_kernel<true>': act_t,
+        'activate_fwd_small_kernel<false>': ds * act_f, 'activate_fwd_chunk_kernel<false>': ds * act_f,
+        'activate_fwd_tiled_kernel<false>': ds * act_f, 'activate_fwd_wide_kernel<false>': ds * act_f,      # (kernels of rounds 1-2)
+        'activate_fwd_small_kernel<true>': act_t, 'activate_fwd_chunk_kernel<true>': act_t,
+        'activate_fwd_tiled_kernel<true>': act_t, 'activate_fwd_wide_kernel<true>': act_t,
         'activate_bwd_tiled_kernel': act_b, 'activate_bwd_wide_kernel': act_b,
         'persample_gram_all_kernel': ds * clip,
         # (+ the cond slices' transposed gradient addend in and transposed copy out, moved by the same launch)
