@@ -206,6 +206,9 @@ class StepEngine(object):
         self.weight_clip = float(weight_clip)
         self._ar_hook = None
         self._head_pending = None
+        # the generator's weight-gradient products as ONE grouped launch behind its backward chain (0.664 -> 0.655 ms per
+        # step at T1M: before, three products of 17-58 us each overlapped one another and the chain's last kernels)
+        self.group_gweights = os.environ.get('DPCGAN_GROUP_GW', '1') == '1'
         self.want_interp_scores = False      # compute the discriminator's scores of the penalty's interpolates (diagnostic: _defer_head)
         self._ar_fault = None
         self._early_hook = None
@@ -1380,9 +1383,10 @@ class StepEngine(object):
         # backward launches and the output layer's column sum on this branch, so that no column-sum launch is left in
         # front of the Adam step - 0.693 -> 0.701 ms: 256 row chunks adding to the same 256 addresses serialise in L2
         # and lengthen the two BatchNorm-backward launches of the critical chain by more than the launch they save)
+        gw_group = self.group_gweights and self.sparse_cond and not self.deterministic
         with self._fork(0, 5):
             self._probe('g_out_dweight_branch')
-            self._gen_dweight(c, L, self.dfake)
+            self._gen_dweight(c, L, self.dfake, what=2 if gw_group else 3)
             self._flush_head()
         count = float(self.gB)
         for l in range(L - 1, -1, -1):
@@ -1404,6 +1408,22 @@ class StepEngine(object):
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
                 self._mm(self.dZ[l], Wl[:, :w_hid], self.dHg[:, self.start[l]:hid], beta=1.0, **bn_back(l - 1))
+            if gw_group:
+                # every layer's weight-gradient product in ONE grouped launch behind the chain (ops.gemm_group), the
+                # row sums of each layer on a branch as soon as its delta exists, the bias sums beside the group
+                with self._fork((L - l) % 2, 6) as part:
+                    self._gen_dweight(c, l, self.dZ[l], what=2)
+                    if l == 0:
+                        self._gen_bias_grads(part)
+                if l == 0:
+                    dys = [self.dfake] + [self.dZ[k] for k in range(L - 1, -1, -1)]
+                    descs = []
+                    for k, dyk in zip(range(L, -1, -1), dys):
+                        gwk = g.G('seq.%d.fc.weight' % k if k < L else 'seq.%d.weight' % L)
+                        descs.append(ops.gemm_desc(dyk, c.Hg[:, self.start[k]:self.Wtot - self.C], gwk[:, :gwk.shape[1] - self.C],
+                                                   trans_a=True, beta=1.0, splitk=0, tile=64))
+                    ops.gemm_group(descs)
+                continue
             if l == 0:
                 # the step's last layer: nothing is left for the main stream, so it takes the row sums and the
                 # bias gradients of every layer (one launch pair) while the product runs beside it
@@ -1413,7 +1433,8 @@ class StepEngine(object):
             else:
                 with self._fork((L - l) % 2, 6):                   # after the chain's product, as above
                     self._gen_dweight(c, l, self.dZ[l])
-        self._gen_bias_grads(self.part)
+        if not gw_group:
+            self._gen_bias_grads(self.part)
         self._join()
         self._probe('g_grads_done')
         fused = update and self._adam_slices_g()
