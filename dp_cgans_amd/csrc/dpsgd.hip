@@ -211,6 +211,7 @@ __device__ __forceinline__ void cond_gram_counts(const GramAllArgs& a, int64_t i
 // Infinity Cache).  Here a short item belongs to ONE wave (item k to wave k % GA_WAVES: the items proceed side by
 // side), a long one (>= GA_LONG floats per row: the K0-wide input rows) is strided over all waves; every wave
 // leaves its wave-summed fp64 entries in LDS, ONE barrier, and thread 0 combines the layers.
+// (GA_WAVES 8 - one item per wave, the whole chip's wave slots in one round - measured in round 3: 13 -> 19.7 us)
 #define GA_WAVES 4
 #define GA_LONG 1024
 __global__ __launch_bounds__(64 * GA_WAVES) void persample_gram_all_kernel(GramAllArgs a) {
