@@ -4,6 +4,7 @@
 // row reductions; reductions accumulate in fp64 and are bit-reproducible (fixed partial layout,
 // fixed summation order, no atomics).
 #include "dpc_common.h"
+#include "../../include/dpcgan_hip.h"
 #include <mutex>
 
 // ---------------------------------------------------------------------------------------------
@@ -111,10 +112,17 @@ struct MultiColArgs {
   int fin0[DPC_MAX_COLSUMS + 1];        // ... in the finish launch (strips blocks each)
   int64_t part0[DPC_MAX_COLSUMS];       // offset of problem p's partials
   double* part; int n; int accumulate;
+  int adv_on; dpc_step_advance adv;     // end-of-step bookkeeping riding in this launch (dpc_colsum_multi_adv)
 };
 
 __global__ __launch_bounds__(256) void colsum_multi_partial_kernel(MultiColArgs a) {
   __shared__ double red[4][64];
+  if (a.adv_on && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.adv.rng_a) a.adv.rng_a[1] += 1;
+    if (a.adv.rng_b) a.adv.rng_b[1] += 1;
+    if (a.adv.t_a) a.adv.t_a[0] += a.adv.add_a;
+    if (a.adv.t_b) a.adv.t_b[0] += a.adv.add_b;
+  }
   int p = 0;
   while (p + 1 < a.n && (int)blockIdx.x >= a.blk0[p + 1]) ++p;
   const int local = blockIdx.x - a.blk0[p];
@@ -170,11 +178,19 @@ __global__ __launch_bounds__(256) void colsum_multi_finish_kernel(MultiColArgs a
 extern "C" int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
                                 const float* const* w, float* const* out, int accumulate, double* part,
                                 int64_t part_cap, void* stream) {
+  return dpc_colsum_multi_adv(n, x, ldx, rows, F, w, out, accumulate, part, part_cap, nullptr, stream);
+}
+
+extern "C" int dpc_colsum_multi_adv(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
+                                    const float* const* w, float* const* out, int accumulate, double* part,
+                                    int64_t part_cap, const dpc_step_advance* adv, void* stream) {
   DPC_CHECK_ARG(n >= 1 && n <= DPC_MAX_COLSUMS, "colsum_multi: 1..8 sums");
   DPC_CHECK_ARG(x && ldx && rows && F && w && out && (part || accumulate == 2), "colsum_multi: null pointer");
   DPC_CHECK_ARG(accumulate >= 0 && accumulate <= 2, "colsum_multi: accumulate must be 0, 1 or 2");
   MultiColArgs a;
   a.n = n; a.part = part; a.accumulate = accumulate;
+  a.adv_on = adv != nullptr;
+  a.adv = adv ? *adv : dpc_step_advance{};
   int blk = 0, fin = 0;
   int64_t off = 0;
   for (int p = 0; p < n; ++p) {

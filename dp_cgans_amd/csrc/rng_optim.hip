@@ -430,7 +430,7 @@ static int adam_fill(AdamArgs& a, float* p, float* g, float* m, float* v, int64_
                      uint32_t site) {
   DPC_CHECK_ARG(p && g && m && v, "adam: null pointer");
   DPC_CHECK_ARG(n >= 0, "adam: negative size");
-  DPC_CHECK_ARG(t_host >= 1, "adam: step count offset must be >= 1");
+  DPC_CHECK_ARG(t_host >= 1 || (t_host == 0 && t_dev), "adam: step count offset must be >= 1 (0 with a device counter that has been bumped already)");
   DPC_CHECK_ARG(nseg == 0 || (seg_off && seg_add), "adam: segment table missing");
   DPC_CHECK_ARG(noise_scale == 0.f || noise_inj || rng, "adam: noise requested without a source");
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;

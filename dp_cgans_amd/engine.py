@@ -209,6 +209,8 @@ class StepEngine(object):
         # the generator's weight-gradient products as ONE grouped launch behind its backward chain (0.664 -> 0.655 ms per
         # step at T1M: before, three products of 17-58 us each overlapped one another and the chain's last kernels)
         self.group_gweights = os.environ.get('DPCGAN_GROUP_GW', '1') == '1'
+        self.advance_in_colsum = os.environ.get('DPCGAN_ADV_COLSUM', '1') == '1'
+        self._adv_pending, self._adv_done = None, False
         self.want_interp_scores = False      # compute the discriminator's scores of the penalty's interpolates (diagnostic: _defer_head)
         self._ar_fault = None
         self._early_hook = None
@@ -657,7 +659,14 @@ class StepEngine(object):
         L = self.L
         probs = [(self.dZ[l], None, self.gen.G('seq.%d.fc.bias' % l)) for l in range(L)]
         probs.append((self.dfake, None, self.gen.G('seq.%d.bias' % L)))
-        ops.colsum_multi(probs, part, atomic=not self.deterministic)      # (into the zeroed gradient pool)
+        adv = None
+        if self._adv_pending is not None:
+            # the step's closing bookkeeping rides in this launch (train_step): the last launch but the Adam step's,
+            # and nothing beside or behind it draws numbers or reads the counters except that Adam step (t_host = 0)
+            adv = ops.step_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=self._adv_pending,
+                                   t_b=self.gen.t, add_b=1)
+            self._adv_pending, self._adv_done = None, True
+        ops.colsum_multi(probs, part, atomic=not self.deterministic, advance=adv)      # (into the zeroed gradient pool)
 
     def _bn_sums(self, c, l, acc):
         """BatchNorm column sums of c.Z[l] for the fused normalisation kernel: -> (workspace, row chunks).  With
@@ -1460,10 +1469,10 @@ class StepEngine(object):
             grads = self.dWcT if not (self.deterministic or self.dist.active) else [None] * (self.L + 1)
             ops.adam_step_slices(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, [(W, W.shape[1], W.shape[1] - self.C) for W in Ws],
                                  [(W, W.shape[1] - self.C, self.C, grads[l], self.WcT[l]) for l, W in enumerate(Ws)],
-                                 t_dev=g.t)
+                                 t_dev=g.t, t_host=0 if self._adv_done else 1)
             self._wct_stale = False
             return
-        ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t)
+        ops.adam_step(g.p, g.g, g.m, g.v, self.lr_g, self.wd_g, t_dev=g.t, t_host=0 if self._adv_done else 1)
         self._refresh_wct()
 
     def train_step(self, d_steps=1):
@@ -1498,8 +1507,9 @@ class StepEngine(object):
             self._gen_forward_pair(self.cd, self.cg, 64 * last, 64 * d_steps)
             self._d_back({}, True, last)
             self._join_early()
+            self._adv_pending = d_steps if self.advance_in_colsum else None
             self._g_back({}, True, d_steps)
-            ops.state_advance(self.rng, rng_b=self.rng_shared, t_a=self.disc.t, add_a=d_steps, t_b=self.gen.t, add_b=1)
+            self._finish_advance(d_steps)
             return
         for k in range(d_steps):
             if overlap and k == d_steps - 1:
@@ -1544,9 +1554,18 @@ class StepEngine(object):
             torch.cuda.current_stream(self.dev).wait_stream(self.early)
             with self._fork(1, 7):
                 self._bn_running(self.cg)
+            self._adv_pending = d_steps if self.advance_in_colsum else None
             self._g_back({}, True, d_steps)
         else:
+            self._adv_pending = d_steps if self.advance_in_colsum else None
             self.g_step(sub=d_steps)
+        self._finish_advance(d_steps)
+
+    def _finish_advance(self, d_steps):
+        """End of a training step: the counters' bump, unless the generator's bias-sum launch has carried it."""
+        done, self._adv_done, self._adv_pending = self._adv_done, False, None
+        if done:
+            return
         # (measured and dropped in round 3: this bookkeeping inside the generator's Adam launch - every block takes a
         # ticket when done and the last one bumps the counters, so the one-thread launch goes away: 0.6846 -> 0.688 ms
         # per step.  The returning atomic at the end of each of ~600 short-lived blocks costs the launch more than the

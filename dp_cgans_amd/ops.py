@@ -480,9 +480,23 @@ def colreduce_fold(part, R, width, nsets=1, set_stride=0, out=None, out_stride=0
                out_stride if out is not None else set_stride, _stream())
 
 
-def colsum_multi(problems, part, accumulate=False, atomic=False):
+class StepAdvance(ctypes.Structure):
+    """dpc_step_advance (include/dpcgan_hip.h): state_advance's bookkeeping as an argument of another launch."""
+    _fields_ = [('rng_a', ctypes.c_void_p), ('rng_b', ctypes.c_void_p), ('t_a', ctypes.c_void_p), ('t_b', ctypes.c_void_p),
+                ('add_a', ctypes.c_int), ('add_b', ctypes.c_int)]
+
+
+def step_advance(rng=None, t_a=None, t_b=None, rng_b=None, add_a=1, add_b=1):
+    """The arguments of state_advance as a StepAdvance for colsum_multi(..., advance=)."""
+    a = StepAdvance(_addr(rng), _addr(rng_b), _addr(t_a), _addr(t_b), int(add_a), int(add_b))
+    a._keep = (rng, rng_b, t_a, t_b)
+    return a
+
+
+def colsum_multi(problems, part, accumulate=False, atomic=False, advance=None):
     """problems: [(x [rows, F], w [rows] or None, out [F])], up to 8: out = sum_r w[r] x[r, :], two launches in all;
-    ``atomic``: one launch, the row chunks add into (pre-zeroed / accumulated) out with fp32 atomics."""
+    ``atomic``: one launch, the row chunks add into (pre-zeroed / accumulated) out with fp32 atomics; ``advance`` =
+    step_advance(...): the launch's first block also does the end-of-step bookkeeping (dpc_colsum_multi_adv)."""
     n = len(problems)
     for x, w, out in problems:
         _chk(x, torch.float32, 'x')
@@ -494,10 +508,12 @@ def colsum_multi(problems, part, accumulate=False, atomic=False):
     P = ctypes.c_void_p * n
     I64 = ctypes.c_int64 * n
     I32 = ctypes.c_int * n
-    lib().call('dpc_colsum_multi', n, P(*[_addr(x) for x, _, _ in problems]), I64(*[_ld(x) for x, _, _ in problems]),
+    tail = (_stream(),) if advance is None else (ctypes.byref(advance), _stream())
+    lib().call('dpc_colsum_multi' if advance is None else 'dpc_colsum_multi_adv',
+               n, P(*[_addr(x) for x, _, _ in problems]), I64(*[_ld(x) for x, _, _ in problems]),
                I64(*[x.shape[0] for x, _, _ in problems]), I32(*[x.shape[1] for x, _, _ in problems]),
                P(*[_addr(w) for _, w, _ in problems]), P(*[_addr(o) for _, _, o in problems]), 2 if atomic else int(accumulate), _p(part),
-               part.numel() if part is not None else 0, _stream())
+               part.numel() if part is not None else 0, *tail)
 
 
 def colsum_noalloc(x, out, w=None, accumulate=False):

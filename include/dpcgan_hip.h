@@ -39,6 +39,12 @@ const char* dpc_last_error(void);
  * generators (dp_cgan.py:581, data_sampler.py:211,269) and torch.optim's host step counters. */
 int dpc_state_advance(uint64_t* rng_a, uint64_t* rng_b, int32_t* t_a, int add_a, int32_t* t_b, int add_b,
                       void* stream);
+/* The same bookkeeping as an argument of another launch (dpc_colsum_multi_adv): one node less per step. */
+typedef struct dpc_step_advance {
+  uint64_t* rng_a; uint64_t* rng_b;
+  int32_t* t_a; int32_t* t_b;
+  int add_a, add_b;
+} dpc_step_advance;
 
 /* out[r*ld + c] = draw(r*cols + c).  kind: 0 u32, 1 normal(a, b) f32 (torch.normal,
  * dp_cgan.py:581,673), 2 Exp(1) f32 (Tensor.exponential_ inside F.gumbel_softmax, :307),
@@ -322,6 +328,13 @@ int dpc_colreduce_fold(const double* part, int R, int width, int nsets, int64_t 
 int dpc_colsum_multi(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
                      const float* const* w, float* const* out, int accumulate, double* part, int64_t part_cap,
                      void* stream);
+/* dpc_colsum_multi that also does dpc_state_advance's bookkeeping (adv nullable): its first block bumps the counters
+ * when it starts.  For the LAST column-sum launch of a training step, where no kernel that runs beside or behind it
+ * draws random numbers or reads the step counters - except an optimiser launch told so (t_host = 0: the counter it
+ * reads has been bumped already).  No reference counterpart (host-side counters there). */
+int dpc_colsum_multi_adv(int n, const float* const* x, const int64_t* ldx, const int64_t* rows, const int* F,
+                     const float* const* w, float* const* out, int accumulate, double* part, int64_t part_cap,
+                     const dpc_step_advance* adv, void* stream);
 /* out[f] (+)= sum_r w[r] * x[r*ldx + f] (w nullable = all ones): dpc_colreduce_partial(mode 1, max_R 64) +
  * dpc_colreduce_finish(kind 1) in one call that ALLOCATES NOTHING and takes no workspace: the row-chunk
  * partial sums live in a 4 MiB file-scope device array of the library (one copy per GPU, held until the

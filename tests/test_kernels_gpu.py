@@ -271,6 +271,27 @@ def test_colsum_multi_all_modes(ops):
     ops.colsum_multi(list(zip(xs, ws, at)), None, atomic=True)
     for o, x, w, r in zip(at, xs, ws, refs):
         close(o, r, what='colsum_multi atomic', scale=float((x.double().abs() * (w.double().abs()[:, None] if w is not None else 1.0)).sum(0).max()))
+    # the launch that also carries the end-of-step bookkeeping (dpc_colsum_multi_adv): same sums, counters as
+    # dpc_state_advance leaves them; and the optimiser launch behind it counts from the bumped step (t_host = 0)
+    rng_a, rng_b = ops.new_rng(5, dev()), ops.new_rng(6, dev())
+    rng_c, rng_d = rng_a.clone(), rng_b.clone()
+    ta, tb = torch.full((1,), 4, dtype=torch.int32, device=dev()), torch.full((1,), 9, dtype=torch.int32, device=dev())
+    tc, td = ta.clone(), tb.clone()
+    outs2 = [torch.full((F,), float('nan'), device=dev()) for _, F, _ in shapes]
+    ops.colsum_multi(list(zip(xs, ws, outs2)), part, advance=ops.step_advance(rng_a, t_a=ta, t_b=tb, rng_b=rng_b, add_a=3, add_b=1))
+    ops.state_advance(rng_c, t_a=tc, t_b=td, rng_b=rng_d, add_a=3, add_b=1)
+    for o, b in zip(outs2, base):
+        assert torch.equal(o, b)
+    assert torch.equal(rng_a, rng_c) and torch.equal(rng_b, rng_d) and torch.equal(ta, tc) and torch.equal(tb, td)
+    assert int(ta.item()) == 7 and int(tb.item()) == 10 and int(rng_a[1].item()) == 1
+    n = 1000
+    mk = lambda: torch.randn(n, generator=g).to(dev())
+    p1, g1, m1, v1 = mk(), mk(), mk() * 0.01, mk().abs() * 0.01
+    p2, m2, v2 = p1.clone(), m1.clone(), v1.clone()
+    t_old = torch.full((1,), 9, dtype=torch.int32, device=dev())
+    ops.adam_step(p1, g1, m1, v1, 2e-4, 1e-6, t_dev=t_old, t_host=1)          # step 10, counted the usual way
+    ops.adam_step(p2, g1, m2, v2, 2e-4, 1e-6, t_dev=tb, t_host=0)             # the counter already says 10
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
 def test_gemm_rejects_bad_arguments(ops):
