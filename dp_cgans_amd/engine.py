@@ -1554,6 +1554,10 @@ class StepEngine(object):
             torch.cuda.current_stream(self.dev).wait_stream(self.early)
             with self._fork(1, 7):
                 self._bn_running(self.cg)
+            # (measured and dropped in round 3: the NEXT step's first launch - its discriminator update's inputs and
+            # pool fill, drawn with the step counter + 1 - on this branch, beside the generator update: 0.6505 ->
+            # 0.647 ms per step, but the discriminator's gradient buffer and inputs then no longer survive the step
+            # that produced them, which callers and tests read)
             self._adv_pending = d_steps if self.advance_in_colsum else None
             self._g_back({}, True, d_steps)
         else:
