@@ -217,6 +217,7 @@ __device__ __forceinline__ void condvec_pair_wave(const CondvecArgs& a, const in
     if (a.sel) { a.sel[2 * b] = ca; a.sel[2 * b + 1] = cb; }
     if (a.gcount) a.gcount[b] = scnt;
   }
+  if (a.cond0 || a.cond1 || a.cond2)        // (a caller that carries the ids in `sel` asks for no dense copy at all)
   for (int c = lane; c < a.C; c += 64) {
     float v = (c == ca || c == cb) ? 1.f : 0.f;
     if (a.cond0) a.cond0[b * a.ld0 + c] = v;

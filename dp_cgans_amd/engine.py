@@ -147,8 +147,10 @@ class GenContext(object):
         self.fake = torch.zeros(B, ldd, **f32)[:, :eng.Dd]
         self.X = X
         self.X3 = X.view(eng.n, eng.K0x)
-        self.cond = torch.zeros(B, max(eng.C, 1), **f32)
-        self.mask = torch.zeros(B, max(eng.nd, 1), device=d, dtype=torch.int32)
+        self._cond = torch.zeros(B, max(eng.C, 1), **f32)
+        self._cond_stale = False      # this context's input launch writes the two hot ids (`sel`) only: `cond` / `mask` are rebuilt from them on access
+        self._mask = torch.zeros(B, max(eng.nd, 1), device=d, dtype=torch.int32)
+        self._eng = eng
         self.pair_id = torch.zeros(B, device=d, dtype=torch.int64)
         self.val_idx = torch.zeros(B, device=d, dtype=torch.int64)
         self.sel = torch.zeros(B, 2, device=d, dtype=torch.int32)
@@ -163,6 +165,34 @@ class GenContext(object):
         self.sums = [None] * len(eng.gdim)       # (workspace, row chunks) of the latest forward's BatchNorm sums
         self.bnacc = None                        # fp64 [2, F] accumulators per layer (inside the engine's zero pools)
 
+
+    @property
+    def cond(self):
+        """The dense two-hot cond matrix [B, C].  A discriminator update that keeps the cond columns off the matrix
+        cores (sparse_cond + sparse_d) never reads it - the ids in ``sel`` are what travels - so its input launch does
+        not write it (590 MB per update at config 5); whoever asks for it afterwards gets it built from the ids."""
+        self._materialise()
+        return self._cond
+
+    @property
+    def mask(self):
+        """[B, nd] int32, 1 at the two discrete columns the cond vector was drawn for (the cond loss reads it); lazy
+        like ``cond``."""
+        self._materialise()
+        return self._mask
+
+    def _materialise(self):
+        if self._cond_stale:
+            ids = self.sel.long()
+            self._cond.zero_()
+            self._cond.scatter_(1, ids, 1.0)
+            # discrete column of a cond id: the last column whose first id is <= it
+            st = self._eng.sampler.cond_st.long()
+            col = torch.searchsorted(st, ids.reshape(-1), right=True).reshape(ids.shape) - 1
+            self._mask.zero_()
+            self._mask.scatter_(1, col, 1)
+            # (the flag stays: a replayed step graph rewrites the ids without running this Python code, so as long as
+            # the context's inputs come from launches that skip the dense copies every access rebuilds them)
 
 class StepEngine(object):
     GP_GRAM = None      # test hook: True / False overrides the automatic choice of the penalty's form
@@ -211,6 +241,7 @@ class StepEngine(object):
         self.group_gweights = os.environ.get('DPCGAN_GROUP_GW', '1') == '1'
         self.advance_in_colsum = os.environ.get('DPCGAN_ADV_COLSUM', '1') == '1'
         self._adv_pending, self._adv_done = None, False
+        self.lazy_cond = os.environ.get('DPCGAN_LAZY_COND', '1') == '1'
         self.want_interp_scores = False      # compute the discriminator's scores of the penalty's interpolates (diagnostic: _defer_head)
         self._ar_fault = None
         self._early_hook = None
@@ -530,7 +561,21 @@ class StepEngine(object):
             # row at the top of the step's critical path otherwise) with the same draws as the separate calls below
             s = self.sampler
             fake_c = None if self.sparse_d else c.X[:, Dd:]
-            ops.step_inputs(s.cnt, s.cond_st, s.dims, s.N, B, [c.cond, cv] + ([] if fake_c is None else [fake_c]), c.mask,
+            # dense copies of the cond vector only where something reads them: the cond columns of Hg when the
+            # generator's Linears multiply them (not sparse_cond), the discriminator input's when its first Linear
+            # does (not sparse_d), the matrix itself for the generator update's cond loss - a discriminator update
+            # with both sparse forms needs none (config 5: 2 x 590 MB per update, 385 -> ~100 us for this launch)
+            dsts = []
+            c._cond_stale = False
+            if not need_real or not (self.sparse_cond and self.sparse_d) or not self.lazy_cond:
+                dsts.append(c._cond)
+            else:
+                c._cond_stale = True
+            if not self.sparse_cond or not self.lazy_cond:
+                dsts.append(cv)
+            if fake_c is not None:
+                dsts.append(fake_c)
+            ops.step_inputs(s.cnt, s.cond_st, s.dims, s.N, B, dsts, None if c._cond_stale else c._mask,
                             c.pair_id, c.val_idx, c.sel, c.gcount, self.rng, ops.SITE_CONDVEC + self._so, z=zv,
                             site_z=ops.SITE_Z + self._so, zero=zero)
             self._join()
@@ -557,6 +602,7 @@ class StepEngine(object):
                     ops.row_gather(self.sampler.table, self.row_id, real, Dd)
             return
         fake_c = None if self.sparse_d else c.X[:, Dd:]     # (sparse_d: the cond columns travel as c.sel)
+        c._cond_stale = False
         if 'cond' in inj:
             c.cond.copy_(inj['cond'])
             c.mask.copy_(inj['mask'])
