@@ -348,6 +348,9 @@ class StepEngine(object):
         self.seg = (self.Dd, self.P, self.row)              # segment map of W1's data columns (ops.gemm_desc)
         xrow = self.P if self.sparse_d else self.row
         self.K0x = pac * xrow                               # length of a stored discriminator-input row
+        # _d_back: the penalty's (u^T diag u) W1 behind the grouped weight gradients instead of beside them (wide first layers)
+        ps = os.environ.get('DPCGAN_PEN_SERIAL', 'auto')
+        self.pen_serial = (self.K0 * self.ddim[0] >= (8 << 20)) if ps == 'auto' else ps == '1'
         self.Xd = torch.zeros((2 if self.sparse_d else 3) * B, xrow, **f32)
         self.Xd3 = self.Xd.view(-1, self.K0x)
         self.Xg = torch.zeros(B, xrow, **f32)               # discriminator input of the generator update
@@ -622,7 +625,9 @@ class StepEngine(object):
             self._draw_real(inj, need_real, c)
 
     def _draw_real(self, inj, need_real, c):
-        """Real rows that match the cond vectors of ``c`` (data_sampler.py:382-396) on a side branch."""
+        """Real rows that match the cond vectors of ``c`` (data_sampler.py:382-396) on a side branch.
+        (Measured in round 3: the branch held back until the generator's output layer, so that config 5's 630 MB row
+        gather does not run beside the forward's small kernels: 82.0 -> 82.3 ms there, 0.647 -> 0.670 ms at T1M.)"""
         B, Dd, C = self.B, self.Dd, self.C
         real = self.Xd[B:2 * B]
         with self._fork(0, 0):      # beside the generator forward; joined before the interpolation
@@ -1227,16 +1232,18 @@ class StepEngine(object):
                                      rowscale=kscale[0:2 * n] if kscale is not None else None)
                 self._flush_head()
             u = self.Dl[0][gp_rows]
+            pen_serial = self.pen_serial
             with self._fork(0, 3):
                 # the penalty's share of dW1, (u^T diag(f c) u) W1: two small dependent products beside the group (the
                 # d0 x d0 one over n rows has 16 tiles - cut along K so that it brings 128 blocks, not 16); it ADDS to
                 # dW1 while the group's first product does: atomics on both sides
                 self._mm(u, u, self.P1, trans_a=True, beta=1.0, kscale=pen_scale, tile=64, splitk=max(1, min(8, n // 128)))
-                self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0, atomic=True)
+                if not pen_serial:
+                    self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0, atomic=True)
             ks2 = kscale[0:2 * n] if kscale is not None else None
             seg_kw = dict(seg_c=1, seg=self.seg) if self.sparse_d else {}
             descs = [ops.gemm_desc(self.Dl[0][0:2 * n], self.Xd3[0:2 * n], d.G('seq.0.weight'), trans_a=True, beta=1.0,
-                                   kscale=ks2, splitk=0, tile=64, atomic=True, **seg_kw)]
+                                   kscale=ks2, splitk=0, tile=64, atomic=not pen_serial, **seg_kw)]
             prev = self.H[0]
             for i in range(1, M):
                 descs.append(ops.gemm_desc(self.Dl[i], prev, d.G('seq.%d.weight' % (3 * i)), trans_a=True, beta=1.0,
@@ -1244,6 +1251,11 @@ class StepEngine(object):
                 prev = self.H[i]
             ops.gemm_group(descs)
             self._join()
+            if pen_serial:
+                # wide first layers: (u^T diag(f c) u) W1 BEHIND the group, plain read-modify-write instead of atomics on
+                # both sides - W1's gradient is K0 x d0 = 76 M elements at config 5 and the atomic epilogue of this
+                # K = d0 product ran at 22 TF/s (1.76 ms beside the group's 1.41 ms)
+                self._mm(self.P1, W1, d.G('seq.0.weight'), beta=1.0)
             self._d_grads_tail(update, inj, sub)
             return
         with self._fork(1, 2) as part:

@@ -559,3 +559,28 @@ def test_lazy_cond_and_mask_equal_what_the_dense_launch_writes():
         gb.run()
         assert torch.equal(a.cd.cond, b.cd.cond) and torch.equal(a.cd.mask, b.cd.mask)
         assert torch.equal(a.cg.cond, b.cg.cond) and torch.equal(a.cg.mask, b.cg.mask)
+
+
+def test_penalty_product_behind_the_group_equals_the_one_beside_it():
+    """StepEngine.pen_serial (wide first layers: (u^T diag(f c) u) W1 added to W1's gradient AFTER the grouped
+    weight-gradient launch with plain stores, instead of beside it with atomics on both sides): same gradient of
+    every discriminator tensor on the same draws, to the 2e-5 gradient bar."""
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+    grads = []
+    for serial in (False, True):
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 120, 10, dev, private=True, dp_mode='dpsgd', seed=5)
+        eng.pen_serial = serial
+        eng.sampler = DataSampler(enc, span, device=dev, seed=4)
+        eng.d_step(update=False)
+        torch.cuda.synchronize()
+        grads.append({k: eng.disc.G(k).clone() for k in eng.disc.keys})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30), k
+    assert float(grads[0]['seq.0.weight'].abs().max()) > 0
+
