@@ -221,9 +221,18 @@ def gemm_run(descs):
                                        shapes=[d._shape for d in descs]),)
 
 
-def gemm_group(descs):
+def gemm_group(descs, fill=768):
     """INDEPENDENT products (list of gemm_desc results) in as few launches as their kernels allow (dpc_gemm_f32_group)."""
     n = len(descs)
+    # Split-K for the GROUP, not per product: the library's cost model sizes each product's K split as if it had the
+    # chip to itself, and the sum then overshoots one round of resident blocks (3 per CU: 768) - the generator's three
+    # weight gradients came to 1240 blocks = 1.6 rounds (69.8 us; 59.7 us with 92 tiles x 8 = 736 blocks).  Products
+    # that asked for the automatic split get fill // tiles when that is at least 2; larger groups keep the model's.
+    tiles = sum(((d.M + 63) // 64) * ((d.N + 63) // 64) for d in descs)
+    if tiles * 2 <= fill:
+        for d in descs:
+            if d.splitk == 0:
+                d.splitk = max(1, min(fill // tiles, d.K // 64))
     arr = (GemmDesc * n)(*descs)
     L = lib()
     L.call('dpc_gemm_f32_group', ctypes.byref(arr), n, _stream())
