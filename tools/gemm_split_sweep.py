@@ -9,6 +9,10 @@ from dp_cgans_amd._lib import lib
 
 dev = torch.device('cuda:0')
 SHAPES = [
+    ('G1 = W1 W1^T NT', 256, 256, 4888, False, True),          # round 3: the step's split products at their current shapes
+    ('D fwd l0 x  NT', 2048, 256, 2816, False, True),
+    ('G D fwd l0  NT', 1024, 256, 2816, False, True),
+    ('P1 u^T u    TN', 256, 256, 1024, True, False),
     ('D fwd l0   NT', 3072, 256, 4888, False, True),
     ('D dW1      TN', 256, 4888, 3072, True, False),
     ('GP v1      NT', 1024, 256, 4888, False, True),
