@@ -574,7 +574,9 @@ class StepEngine(object):
                 dsts.append(c._cond)
             else:
                 c._cond_stale = True
-            if not self.sparse_cond or not self.lazy_cond:
+            # (the reproducible mode's generator backward takes the DENSE weight-gradient product over all of Hg,
+            # cond columns included: _gen_dweight)
+            if not self.sparse_cond or not self.lazy_cond or (not need_real and self.deterministic):
                 dsts.append(cv)
             if fake_c is not None:
                 dsts.append(fake_c)

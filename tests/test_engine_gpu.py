@@ -584,3 +584,36 @@ def test_penalty_product_behind_the_group_equals_the_one_beside_it():
         assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30), k
     assert float(grads[0]['seq.0.weight'].abs().max()) > 0
 
+
+def span_cond_width(span_info):
+    from oracle.nets import discrete_columns
+    return sum(k for _, _, k in discrete_columns(span_info))
+
+
+def test_reproducible_mode_generator_gradient_sees_the_cond_columns():
+    """deterministic=True keeps the dense weight-gradient products of the generator, which read the cond columns of
+    Hg - so the input launch of a GENERATOR update must still write them there (it skips them in the default mode,
+    where nothing reads them).  Same seeds, Philox-drawn inputs: the two modes' generator gradients agree to the
+    2e-5 gradient bar, cond columns included."""
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+    grads = []
+    for det in (False, True):
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 120, 10, dev, private=False, seed=5, deterministic=det)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=4)
+        eng.g_step(update=False)
+        torch.cuda.synchronize()
+        grads.append({k: eng.gen.G(k).clone() for k in eng.gen.keys})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if k.endswith('fc.bias'):        # a Linear bias in front of BatchNorm has gradient zero: rounding noise on both sides
+            assert float(a.abs().max()) < 1e-7 and float(b.abs().max()) < 1e-7, k
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30), k
+    w0 = grads[1]['seq.0.fc.weight']
+    assert float(w0[:, -span_cond_width(span):].abs().max()) > 0
+
