@@ -617,3 +617,26 @@ def test_reproducible_mode_generator_gradient_sees_the_cond_columns():
     w0 = grads[1]['seq.0.fc.weight']
     assert float(w0[:, -span_cond_width(span):].abs().max()) > 0
 
+
+@pytest.mark.parametrize('mode', ['dpsgd', 'reference'])
+def test_reproducible_mode_discriminator_gradient_equals_the_default_mode(mode):
+    """The reproducible mode (dense products, fixed-order reductions, no sparse first layer) and the default mode
+    (hot-id forms, grouped launches, atomics) are two routes to the same discriminator gradient: same seeds,
+    Philox-drawn inputs, every tensor to the 2e-5 gradient bar."""
+    from golden_util import load
+    from dp_cgans_amd.data_sampler import DataSampler
+    from dp_cgans_amd.engine import StepEngine
+    z = load('adult_sampler.npz')
+    enc, span = z['encoded'], z['span_info']
+    dev = torch.device('cuda:0')
+    grads = []
+    for det in (False, True):
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 120, 10, dev, private=True, dp_mode=mode, seed=5, deterministic=det)
+        eng.sampler = DataSampler(enc, span, device=dev, seed=4)
+        eng.d_step(update=False)
+        torch.cuda.synchronize()
+        grads.append({k: eng.disc.G(k).clone() for k in eng.disc.keys})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-30), k
+
