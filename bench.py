@@ -39,6 +39,9 @@ def main():
                          "reference's grad-hook noise + weight clamp")
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
     ap.add_argument('--serial', action='store_true', help='no side streams: the step is one chain of kernels (tuning)')
+    ap.add_argument('--bn-sync', type=int, default=1, choices=[0, 1],
+                    help='N > 1: 1 = BatchNorm statistics over the global batch (6 all-reduces per step, the default), '
+                         '0 = per-rank statistics as DistributedDataParallel does (2 all-reduces per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--devices', default=None,
@@ -102,7 +105,7 @@ def main():
     sampler = DataSampler(table, span, device=dev, seed=17 + dist.rank)
     progress('sampler tables built')
     eng = StepEngine(span, 128, dims, dims, args.batch, args.pac, dev, private=True, seed=0, dist=dist,
-                     dp_mode=args.dp_mode, dp_sigma=1.0, dp_clip=1.0)
+                     dp_mode=args.dp_mode, dp_sigma=1.0, dp_clip=1.0, bn_sync=bool(args.bn_sync))
     eng.sampler = sampler
     if args.serial:
         eng.concurrent = False
@@ -137,6 +140,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload,
                    'global_batch': args.batch * dist.world, 'parallelism': 'dp%d' % dist.world,
+                   'batchnorm': ('statistics over the global batch' if eng.bn_sync else 'per-rank statistics') if dist.active else 'one rank',
                    'launch': 'eager' if args.no_graph else 'hipGraph replay (%d graph segment(s)%s)' % (
                        sum(1 for k, _ in (gstep.items or []) if k == 'graph'),
                        '' if not dist.active else (', RCCL all-reduces captured in the graph' if gstep.collectives_in_graph

@@ -201,7 +201,7 @@ class StepEngine(object):
     def __init__(self, span_info, embedding_dim, generator_dim, discriminator_dim, batch_size, pac, device,
                  generator_lr=2e-4, generator_decay=1e-6, discriminator_lr=2e-4, discriminator_decay=1e-6,
                  private=False, seed=None, dist=None, global_batch=None, dp_mode='reference', dp_sigma=1.0, dp_clip=1.0,
-                 weight_clip=None, gp_gram=None, sparse_cond=None, deterministic=None):
+                 weight_clip=None, gp_gram=None, sparse_cond=None, deterministic=None, bn_sync=True):
         self.dev = torch.device(device)
         self.dist = dist or NoDist()
         if seed is None:
@@ -220,6 +220,13 @@ class StepEngine(object):
         if batch_size % pac != 0:
             raise AssertionError('batch_size %% pac != 0')      # dp_cgan.py:67
         self.gB = global_batch or batch_size * self.dist.world
+        # Data parallel, the generator's BatchNorm: bn_sync=True normalises with the statistics of the GLOBAL batch (one
+        # all-reduce per layer and direction: the step equals the single-process step on the concatenated batch);
+        # False is what DistributedDataParallel does by default - every rank normalises its own rows, the only exchanges
+        # left are the two gradient all-reduces, and the step runs on the single-GPU schedule.
+        self.bn_sync = bool(bn_sync)
+        self.bn_dist = self.dist.active and self.bn_sync
+        self.bn_count = float(self.gB if (self.bn_sync or not self.dist.active) else batch_size)
         self.n = batch_size // pac
         self.gn = self.gB // pac
         self.gdim, self.ddim = list(generator_dim), list(discriminator_dim)
@@ -733,7 +740,7 @@ class StepEngine(object):
         """Generator forward into context ``c``.  ``running`` False leaves BatchNorm's running
         statistics alone (``_bn_running`` applies the update later, from the column sums kept for it)."""
         g = self.gen
-        count = float(self.gB)
+        count = self.bn_count
         for l in range(self.L):
             self._gen_linear(c, l, c.Z[l], g.P('seq.%d.fc.bias' % l), colstat=c.bnacc[l] if self.fused_stats else None)
             part, R = self._bn_sums(c, l, c.bnacc[l])
@@ -758,7 +765,7 @@ class StepEngine(object):
         returns - ``_join_early`` (called by the next collective and before the generator update's
         backward) brings them back."""
         g = self.gen
-        count = float(self.gB)
+        count = self.bn_count
         main = torch.cuda.current_stream(self.dev)
         lanes = self.concurrent and self.early is not None
         if self.sparse_cond and (self._wct_stale or self.gen.loaded):
@@ -835,7 +842,7 @@ class StepEngine(object):
     def _bn_running(self, c):
         """The running-statistics update a ``_gen_forward(c, running=False)`` left out, in its place in
         the sequence of forwards (momentum updates do not commute)."""
-        count = float(self.gB)
+        count = self.bn_count
         for l in range(self.L):
             part, R = c.sums[l]
             ops.colreduce_finish(part, R, 2, self.gdim[l], 0, self.bn_scratch[l][0], self.bn_scratch[l][1],
@@ -1112,7 +1119,7 @@ class StepEngine(object):
         """Data parallel: the R row-chunk partials of a BatchNorm column reduction (``part`` [R, width] fp64) become
         the sums over the GLOBAL batch - folded on the device to one vector, then ONE all-reduce of `width` doubles
         (not R x width).  Returns the chunk count to hand to the consumer (1 once folded)."""
-        if not self.dist.active:
+        if not self.bn_dist:
             return R
         if R > 1:
             ops.colreduce_fold(part, R, width)
@@ -1458,7 +1465,7 @@ class StepEngine(object):
             self._probe('g_out_dweight_branch')
             self._gen_dweight(c, L, self.dfake, what=2 if gw_group else 3)
             self._flush_head()
-        count = float(self.gB)
+        count = self.bn_count
         for l in range(L - 1, -1, -1):
             blk = slice(self.start[l + 1], self.start[l])
             dy, yv = self.dHg[:, blk], c.Hg[:, blk]
@@ -1471,9 +1478,10 @@ class StepEngine(object):
             dbeta, dgamma = g.G('seq.%d.bn.bias' % l), g.G('seq.%d.bn.weight' % l)
             # BatchNorm gradients come from all-reduced column sums, i.e. are global already: written
             # times 1/world so that the sum over ranks of the flat gradient buffer leaves them unchanged
+            # (per-rank statistics: local sums, summed by that all-reduce like every other gradient)
             ops.bn_relu_bwd_fused(dy, yv, c.Z[l], sums, R, count, c.bn_mean[l], c.bn_invstd[l],
                                   g.P('seq.%d.bn.weight' % l), dbeta, dgamma, self.dZ[l],
-                                  grad_scale=1.0 / self.dist.world if self.dist.active else 1.0)
+                                  grad_scale=1.0 / self.dist.world if self.bn_dist else 1.0)
             Wl = g.P('seq.%d.fc.weight' % l)
             w_hid = hid - self.start[l]                         # earlier hidden blocks this layer read
             if w_hid > 0:
@@ -1539,8 +1547,8 @@ class StepEngine(object):
         """``d_steps`` discriminator updates and one generator update (one iteration of the
         reference's loop, dp_cgan.py:570-722), then ONE launch that advances both RNG step counters
         and both Adam step counters."""
-        overlap = self.concurrent and self.early is not None and not self.dist.active and d_steps >= 1
-        if self.dist.active and self.pair_forwards and d_steps >= 1:
+        overlap = self.concurrent and self.early is not None and not self.bn_dist and d_steps >= 1
+        if self.bn_dist and self.pair_forwards and d_steps >= 1:
             # data parallel: the two generator forwards of the step's tail share their collectives
             for k in range(d_steps - 1):
                 self.d_step(sub=k)
@@ -1607,11 +1615,12 @@ class StepEngine(object):
                     finally:
                         self._inline = False
                     self._so = so
+                    self._early_open = True     # (a graph cut - eager collectives between segments - joins the lane first)
                 self._early_hook = issue
             self.d_step(sub=k)
         if overlap:
             self._flush_pending()
-            torch.cuda.current_stream(self.dev).wait_stream(self.early)
+            self._join_early()
             with self._fork(1, 7):
                 self._bn_running(self.cg)
             # (measured and dropped in round 3: the NEXT step's first launch - its discriminator update's inputs and

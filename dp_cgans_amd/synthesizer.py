@@ -52,7 +52,10 @@ class DPCGANSynthesizer(object):
 
     Additional keyword arguments of this build: ``dp_mode`` ('reference': the reference's
     private=True, i.e. grad-hook noise + weight clamp; 'dpsgd': per-example clipping + Gaussian
-    noise), ``dp_sigma``, ``dp_clip``, ``seed``, ``use_graph``.
+    noise), ``dp_sigma``, ``dp_clip``, ``seed``, ``use_graph``, ``bn_sync`` (data parallel only: True -
+    the generator's BatchNorm normalises over the global batch and the fit equals the single-process
+    one; False - every rank over its own rows, as DistributedDataParallel does, 2 collectives per step
+    instead of 6).
 
     ``seed=None`` (the default) keys every Philox stream - parameter init, batch draws and the DP
     noise - from OS entropy, as the reference draws from torch's / numpy's unseeded global generators
@@ -71,7 +74,7 @@ class DPCGANSynthesizer(object):
                  discriminator_decay=1e-6, batch_size=500, discriminator_steps=1,
                  log_frequency=True, verbose=False, epochs=300, pac=10, cuda=True, private=False,
                  wandb=False, ontology=None, saved_transformer=None, dp_mode='reference', dp_sigma=1.0,
-                 dp_clip=1.0, seed=None, use_graph=True):
+                 dp_clip=1.0, seed=None, use_graph=True, bn_sync=True):
         assert batch_size % 2 == 0                      # dp_cgan.py:241
 
         self._embedding_dim = embedding_dim
@@ -94,6 +97,7 @@ class DPCGANSynthesizer(object):
         self.dp_mode, self.dp_sigma, self.dp_clip = dp_mode, dp_sigma, dp_clip
         self.seed = seed
         self.use_graph = use_graph
+        self.bn_sync = bn_sync
 
         if private and seed is not None:
             warnings.warn('DPCGANSynthesizer(private=True, seed=%r): a fixed seed makes the DP noise a reproducible, '
@@ -171,7 +175,7 @@ class DPCGANSynthesizer(object):
                          self.pac, self._device, generator_lr=self._generator_lr, generator_decay=self._generator_decay,
                          discriminator_lr=self._discriminator_lr, discriminator_decay=self._discriminator_decay,
                          private=self.private, seed=base_seed, dist=dist, global_batch=self._batch_size,
-                         dp_mode=self.dp_mode, dp_sigma=self.dp_sigma, dp_clip=self.dp_clip)
+                         dp_mode=self.dp_mode, dp_sigma=self.dp_sigma, dp_clip=self.dp_clip, bn_sync=self.bn_sync)
         self._engine = eng
         self._generator = _Net(eng.generator_state_dict, eng.load_generator_state_dict)
         self._discriminator = _Net(eng.discriminator_state_dict, eng.disc.load)

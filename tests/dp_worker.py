@@ -135,7 +135,96 @@ def replay_dpsgd(dist, dev, clip_quantile):
     assert torch.equal(chk, eng.disc.p * R), 'replicas diverged: the noise was not added identically on every rank'
 
 
-def graph(dist, dev, mode):
+def local_bn(dist, dev):
+    """bn_sync=False - every rank's BatchNorm over its OWN rows, which is what DistributedDataParallel computes: the
+    first discriminator update and the first generator update of the reference trace, sharded by rows.  Expected
+    gradients: the mean over ranks of the single-process oracle run on each rank's shard as a batch of its own (the
+    loss means are global means = means of the shard means); running statistics: the oracle's on this rank's shard."""
+    from golden_util import Trace
+    from dp_cgans_amd.engine import StepEngine
+    from oracle import nets as onets
+    from test_engine_gpu import close, injected
+    tr = Trace('trace_np.npz')
+    R, r = dist.world, dist.rank
+    sD, sG = tr.kinds.index('D'), tr.kinds.index('G')
+    dp = {k: torch.from_numpy(v) for k, v in tr.params(sD, 'p_before').items()}
+    gp = {k: torch.from_numpy(v) for k, v in tr.params(sG, 'p_before').items()}
+    n = tr.B // tr.pac
+    eng = StepEngine(tr.span_info, tr.E, tr.gen_dim, tr.disc_dim, tr.B // R, tr.pac, dev, private=False, dist=dist,
+                     global_batch=tr.B, bn_sync=False)
+    assert not eng.bn_dist and eng.bn_count == tr.B // R
+    eng.disc.load(dp)
+    eng.gen.load(gp)
+    L = onets.n_residual(gp)
+    bn_state = {}
+    for l in range(L):
+        F_ = gp['seq.%d.bn.weight' % l].shape[0]
+        bn_state['seq.%d.bn.running_mean' % l] = torch.zeros(F_)
+        bn_state['seq.%d.bn.running_var' % l] = torch.ones(F_)
+        bn_state['seq.%d.bn.num_batches_tracked' % l] = torch.zeros((), dtype=torch.int64)
+
+    # --- discriminator update
+    full = injected(tr, sD, dev)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [m.cpu() for m in v]) for k, v in full.items()}
+    real_cond = cpu['cond'][cpu['perm']]
+
+    def d_grads(q, state):
+        sh = lambda x: shard(x, q, R)
+        mk = lambda b: [sh(m[b * n:(b + 1) * n]) for m in cpu['keep']]
+        dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+        fake = onets.gen_forward(gp, torch.cat([sh(cpu['z']), sh(cpu['cond'])], 1), state)
+        act = onets.apply_activate(fake, tr.span_info, sh(cpu['exp']))
+        fake_cat, real_cat = torch.cat([act, sh(cpu['cond'])], 1), torch.cat([sh(cpu['real']), sh(real_cond)], 1)
+        fake_cat = fake_cat.detach().requires_grad_(True)      # (the penalty differentiates with respect to its input rows)
+        loss = -(onets.disc_forward(dpl, real_cat, tr.pac, mk(1)).mean() - onets.disc_forward(dpl, fake_cat, tr.pac, mk(0)).mean())
+        pen = onets.gradient_penalty(dpl, real_cat, fake_cat, tr.pac, sh(cpu['alpha']), mk(2))
+        keys = list(dpl)
+        gs = torch.autograd.grad(loss + pen, [dpl[k] for k in keys], allow_unused=True)
+        return {k: (torch.zeros_like(dpl[k]) if g is None else g.detach()) for k, g in zip(keys, gs)}
+    per_rank = [d_grads(q, bn_state if q == r else None) for q in range(R)]
+    want = {k: sum(g[k] for g in per_rank) / R for k in per_rank[0]}
+    inj = {k: shard(full[k], r, R) for k in ('z', 'cond', 'mask', 'exp')}
+    inj['keep'] = [torch.cat([shard(m[b * n:(b + 1) * n], r, R) for b in range(3)]) for m in full['keep']]
+    inj['real'] = shard(full['real'], r, R)
+    inj['real_cond'] = shard(full['cond'][full['perm']], r, R)
+    inj['alpha'] = shard(full['alpha'], r, R)
+    eng.d_step(inj)
+    for k in tr.dkeys:
+        close(eng.disc.G(k), want[k], rtol=2e-5, what='rank %d: D grad %s' % (r, k))
+
+    # --- generator update (the engine's discriminator back on the trace's weights for that step)
+    dnow = {k: eng.disc.P(k).detach().cpu().clone() for k in tr.dkeys}
+    full = injected(tr, sG, dev)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [m.cpu() for m in v]) for k, v in full.items()}
+    per_rank = []
+    for q in range(R):
+        sh = lambda x: shard(x, q, R)
+        out = onets.g_step_grads(gp, dnow, tr.span_info, tr.pac, sh(cpu['z']), sh(cpu['cond']), sh(cpu['mask']),
+                                 sh(cpu['exp']), [sh(m) for m in cpu['keep']], bn_state=bn_state if q == r else None,
+                                 loop_loss=False)
+        per_rank.append(out['grads'])
+    want = {k: sum(g[k] for g in per_rank) / R for k in per_rank[0]}
+    inj = {k: shard(full[k], r, R) for k in ('z', 'cond', 'mask', 'exp')}
+    inj['keep'] = [shard(m, r, R) for m in full['keep']]
+    eng.g_step(inj)
+    for k in tr.gkeys:
+        sc = want[k.replace('fc.bias', 'fc.weight')].abs().max().item() if 'fc.bias' in k else None
+        close(eng.gen.G(k), want[k], rtol=2e-5, scale=sc, what='rank %d: G grad %s' % (r, k))
+    sd = eng.generator_state_dict()
+    for k, v in bn_state.items():
+        if 'running' in k:
+            sc = None
+            if k.endswith('running_mean'):
+                sc = max(float(v.abs().max()), float(bn_state[k.replace('running_mean', 'running_var')].sqrt().max()))
+            close(sd[k], v, scale=sc, what='rank %d: %s (this rank\'s rows only)' % (r, k))
+    # the parameters stay replicated (the running statistics are per rank, as under DistributedDataParallel)
+    for net in (eng.disc, eng.gen):
+        chk = net.p.clone()
+        dist.allreduce(chk)
+        assert torch.equal(chk, net.p * R), 'replicas diverged'
+
+
+def graph(dist, dev, mode, bn_sync=True):
     from golden_util import load
     from dp_cgans_amd.data_sampler import DataSampler
     from dp_cgans_amd.engine import GraphStep, StepEngine
@@ -143,7 +232,8 @@ def graph(dist, dev, mode):
     enc, span = z['encoded'], z['span_info']
 
     def make():
-        eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=dist)
+        eng = StepEngine(span, 24, (40, 24), (48, 16), 60, 10, dev, private=True, dp_mode=mode, seed=3, dist=dist,
+                         bn_sync=bn_sync)
         eng.sampler = DataSampler(enc, span, device=dev, seed=9 + dist.rank)
         return eng
     from dp_cgans_amd import ops as _ops
@@ -161,6 +251,9 @@ def graph(dist, dev, mode):
         assert len(gs.items) == 1 and gs.collectives_in_graph, 'RCCL collectives are captured: one graph per step'
     else:
         assert len(gs.items) > 1, 'a data-parallel step must be cut into graph segments at its collectives'
+    if not bn_sync:
+        n_ar = sum(1 for k, _ in gs.items if k != 'graph')
+        assert gs.collectives_in_graph or n_ar == 2, 'per-rank statistics: the two gradient all-reduces are the only exchanges (%d)' % n_ar
     assert torch.equal(a.disc.p, b.disc.p) and torch.equal(a.gen.p, b.gen.p)
     assert torch.equal(a.disc.p, c.disc.p) and torch.equal(a.gen.p, c.gen.p), 'paired forwards changed the step'
     sa, sc = a.generator_state_dict(), c.generator_state_dict()
@@ -278,6 +371,10 @@ def main():
         replay(dist, dev)
     elif mode == 'replay_dpsgd':
         replay_dpsgd(dist, dev, sys.argv[2])
+    elif mode == 'local_bn':
+        local_bn(dist, dev)
+    elif mode == 'graph_local_bn':
+        graph(dist, dev, sys.argv[2], bn_sync=False)
     elif mode == 'fused':
         fused(dist, dev, sys.argv[2])
     elif mode == 'fallback':

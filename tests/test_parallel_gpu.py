@@ -95,6 +95,27 @@ def test_two_ranks_default_step_with_fused_statistics(mode):
     launch(['fused', mode])
 
 
+def test_two_ranks_per_rank_batchnorm_equals_the_mean_of_the_shard_oracles():
+    """bn_sync=False (what DistributedDataParallel computes): each rank normalises over its own rows; the all-reduced
+    gradients equal the mean over ranks of the single-process oracle on each shard, the running statistics are the
+    rank's own, the parameters stay replicated."""
+    launch(['local_bn'])
+
+
+@pytest.mark.parametrize('mode', ['reference', 'dpsgd'])
+def test_two_ranks_per_rank_batchnorm_graph_segments_equal_eager(mode):
+    """... and its graph form: two eager all-reduces (the gradients) between three segments, bit-equal to eager."""
+    launch(['graph_local_bn', mode])
+
+
+@pytest.mark.parametrize('collectives', ['in-graph', 'between-segments'])
+def test_rccl_single_rank_per_rank_batchnorm_graph_replay_equals_eager(collectives):
+    """The single-GPU schedule (generator forward on its own lane beside the discriminator update's tail) with the two
+    gradient all-reduces as graph nodes / as graph cuts that join the lane first."""
+    env = dict(RCCL1, DPCGAN_GRAPH_COLLECTIVES='1' if collectives == 'in-graph' else '0')
+    launch(['graph_local_bn', 'dpsgd'], world=1, extra_env=env)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` started directly: the launcher's two children share cuda:0 here (over gloo), run the
     timed graph-replayed step and rank 0's JSON line comes back through the launcher."""
