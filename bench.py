@@ -39,9 +39,11 @@ def main():
                          "reference's grad-hook noise + weight clamp")
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
     ap.add_argument('--serial', action='store_true', help='no side streams: the step is one chain of kernels (tuning)')
-    ap.add_argument('--bn-sync', type=int, default=1, choices=[0, 1],
-                    help='N > 1: 1 = BatchNorm statistics over the global batch (6 all-reduces per step, the default), '
-                         '0 = per-rank statistics as DistributedDataParallel does (2 all-reduces per step)')
+    ap.add_argument('--bn-sync', type=int, default=0, choices=[0, 1],
+                    help='N > 1 (weak scaling: every rank trains on a batch of the reference\'s own size): 0 = per-rank '
+                         'BatchNorm statistics, what DistributedDataParallel computes - 2 all-reduces per step (default); '
+                         '1 = statistics over the global batch, the step of DPCGANSynthesizer.fit\'s default, which splits '
+                         'ONE batch over the ranks and promises the single-process result - 6 all-reduces per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--devices', default=None,

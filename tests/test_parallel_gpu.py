@@ -116,15 +116,17 @@ def test_rccl_single_rank_per_rank_batchnorm_graph_replay_equals_eager(collectiv
     launch(['graph_local_bn', 'dpsgd'], world=1, extra_env=env)
 
 
-def test_bench_starts_its_own_ranks():
+@pytest.mark.parametrize('bn_sync', [0, 1])
+def test_bench_starts_its_own_ranks(bn_sync):
     """`python bench.py --gpus 2` started directly: the launcher's two children share cuda:0 here (over gloo), run the
-    timed graph-replayed step and rank 0's JSON line comes back through the launcher."""
+    timed graph-replayed step and rank 0's JSON line comes back through the launcher.  Per-rank BatchNorm statistics
+    (the weak-scaling default) leave the two gradient all-reduces, --bn-sync 1 adds the four BatchNorm ones."""
     import json
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--devices', '0,0', '--rows', '20000',
                         '--batch', '512', '--dims', '64,64', '--steps', '3', '--warmup', '2', '--no-roofline',
-                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        '--no-cpu-baseline'] + (['--bn-sync', '1'] if bn_sync else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=400, cwd=root)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -132,4 +134,6 @@ def test_bench_starts_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['value'] > 0 and rec['scaling'] == 'weak'
     assert rec['config']['global_batch'] == 1024 and rec['config']['parallelism'] == 'dp2'
-    assert 'eager all-reduces between them' in rec['config']['launch']      # gloo: graph segments cut at the collectives
+    # gloo: graph segments cut at the collectives
+    assert ('%d eager all-reduces between them' % (6 if bn_sync else 2)) in rec['config']['launch'], rec['config']['launch']
+    assert rec['config']['batchnorm'] == ('statistics over the global batch' if bn_sync else 'per-rank statistics')
