@@ -28,12 +28,14 @@ struct ActFwdArgs {
 // counters showed the three-phase form (rows staged through LDS on the way in and on the way out) VALU-bound at 166
 // instructions per element - library logf / expf / division (now the hardware units, dpc_common.h) and per-element
 // index bookkeeping.
-//   LDS     ts[R][ldT] logits (ldT = Dd rounded up to 4) | spans[3*nspan] | LOSS: col2d[Dd] | col2c[Dd] | mask [R*nd].
+//   LDS     ts[R][ldT] logits (ldT = Dd rounded up to 4, + 8 of padding) | spans[3*nspan] | LOSS: col2d[Dd] | col2c[Dd] | mask [R*nd].
 //   phase 1 one thread per (row, Philox block that touches the row): a row of Dd elements starting at flat index
 //           b*Dd lies in at most nqr = (Dd+3)/4 + 1 blocks; a block on a row boundary is computed by both rows
 //           (2 in ~85), which buys a thread whose four elements share one row - no wrap-around bookkeeping.  The
-//           four raw outputs come straight from global memory (consecutive threads, consecutive addresses) while
-//           the Philox block is computed; t = (x - log E) / tau goes to LDS.
+//           four raw outputs come straight from global memory in ONE 16-byte load at 4-byte alignment (consecutive
+//           threads, consecutive addresses; a block that hangs over the row reads the neighbouring row's storage)
+//           while the Philox block is computed; t = (x - log E) / tau goes to LDS, all four values unpredicated
+//           (the overhang lands in the row's padding).
 //   phase 2 one thread per (row, span): softmax over the span's LDS values (max, exp, sum in column order, scale
 //           by 1/sum); spans of up to 4 columns - all of them through the reference's public wrapper - stay in
 //           registers; the result goes straight to y (consecutive threads hold consecutive spans: the wave's stores
@@ -43,12 +45,16 @@ struct ActFwdArgs {
 // Rows and items are found from flat indices by a float reciprocal + correction (exact below 2^16; a 32-bit division
 // by a runtime value is ~30 instructions).
 // Measured at T1M's 8192 x 335 (tools/act_bench.py, launches back to back in a graph): 20.7 -> 14.0 us, with the loss
-// 37 -> 23.5 us; a plain copy of the same bytes takes 4.7 us.  With phases switched off one at a time: reading the
+// 37 -> 23.5 us; then 11.9 / 22.1 us once the injected-draws pointer stopped aliasing x (`er = en ? en : x` made every
+// thread load its four raw values twice: 14.0 -> 12.3 us), the four clamped 4-byte loads became one 16-byte load
+// (-> 12.05) and the LDS stores lost their predicates (-> 11.9).  A plain copy of the same bytes takes 4.7 us.  With phases switched off one at a time: reading the
 // rows into LDS alone 7.6 us, + coalesced stores 10.7 us (the load -> barrier -> store skeleton at ~20 KB in flight
 // per CU is latency-bound), Philox + logs 1.1 us, the span pass 5.5 us (12.7 us with the loss: one L2 round trip per
 // pass of its item loop).  Tried on top and not kept: raw rows and the tile's cond rows staged in LDS with span-owner
 // threads walking the rows (no global load in phase 2: 13.7 / 27-31 us), two items per thread with both items'
 // loads issued first (+-0), 16-byte staging loads with padded LDS rows (+-0).
+typedef float act_f4u __attribute__((ext_vector_type(4), aligned(4)));      // four floats at any 4-byte alignment
+
 __device__ __forceinline__ uint32_t act_div(uint32_t x, uint32_t d, float inv_d) {
   uint32_t q = (uint32_t)((float)x * inv_d);
   if ((q + 1) * d <= x) ++q;
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, i
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ double red[16];
   const uint32_t Dd = (uint32_t)a.Dd, R = (uint32_t)a.R, nspan = (uint32_t)a.nspan;
-  const uint32_t ldT = (Dd + 3u) & ~3u;
+  const uint32_t ldT = ((Dd + 3u) & ~3u) + 8u;      // 4 floats of padding in front of a row's logits, 4+ behind (phase 1)
   const uint32_t nqr = ((Dd + 3u) >> 2) + 1u;
   float* ts = tile;
   int32_t* sp = reinterpret_cast<int32_t*>(ts + R * ldT);
@@ -95,25 +101,30 @@ __global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, i
       const int c0 = (int)(j << 2) - (int)((uint32_t)fr & 3u);     // column of the block's first element
       if (c0 >= (int)Dd) continue;                                 // (the row ends one block earlier)
       const float* __restrict__ xr = xg + r * a.ldx;
-      const float* __restrict__ er = a.en ? a.en + (b0 + r) * a.ld_en : xr;
       float xv[4], ev[4];
+      // The block's four raw values in ONE 16-byte load (any 4-byte alignment).  A block that hangs over the row's
+      // first or last column reads the neighbouring row's storage (ldx >= Dd: it exists) - except in the matrix's very
+      // first and last row, whose overhanging blocks clamp their columns instead.
+      if ((c0 >= 0 || b0 + r > 0) && (c0 + 3 < (int)Dd || b0 + r + 1 < a.B)) {
+        const act_f4u q = *reinterpret_cast<const act_f4u*>(xr + c0);
+        xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+      } else {
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {                                // (columns clamped into the row: no branch per load)
-        const int col = min(max(c0 + l, 0), (int)Dd - 1);
-        xv[l] = xr[col];
-        ev[l] = er[col];
+        for (int l = 0; l < 4; ++l) xv[l] = xr[min(max(c0 + l, 0), (int)Dd - 1)];
       }
-      if (!a.en) {
+      if (a.en) {                                                  // injected Exp(1) draws (tests): a uniform branch
+        const float* __restrict__ er = a.en + (b0 + r) * a.ld_en;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) ev[l] = er[min(max(c0 + l, 0), (int)Dd - 1)];
+      } else {
         const DpcPhilox4 ph = dpc_philox(a.rng[0], a.rng[1], a.site, (fr >> 2) + j);
 #pragma unroll
         for (int l = 0; l < 4; ++l) ev[l] = dpc_exp1(ph.v[l]);
       }
-      float* tr = ts + r * ldT;
+      // all four values are stored: what hangs over the row (c0 in -3 .. Dd-1) lands in the row's padding
+      float* tr = ts + r * ldT + 4u + c0;
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const int col = c0 + l;
-        if (col >= 0 && col < (int)Dd) tr[col] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
-      }
+      for (int l = 0; l < 4; ++l) tr[l] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
     }
     __syncthreads();
     // ---- phase 2: one thread per (row, span)
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void activate_fwd_small_kernel(ActFwdArgs a, i
     for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
       const uint32_t r = act_div(it, nspan, inv_ns), s = it - r * nspan;
       const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
-      const float* tr = ts + r * ldT + off;
+      const float* tr = ts + r * ldT + 4u + off;
       const float* __restrict__ xr = xg + r * a.ldx + off;
       float* __restrict__ yr = a.y + (b0 + r) * a.ldy + off;
       float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + (b0 + r) * a.lddf + off : nullptr;
@@ -311,6 +322,14 @@ __device__ __forceinline__ void act_span_direct(const ActFwdArgs& a, int64_t b, 
 // and row.  Chunks are the fast index: neighbouring blocks work on neighbouring columns of the same rows.  A chunk
 // whose R rows exceed the LDS tile (spans hundreds of columns wide) takes its spans straight from global memory
 // (act_span_direct) - always correct, fast for the tables the reference's wrapper produces (2-column spans).
+// Phase 2 here: thread s owns span s of the chunk (at most 256 = the block) and walks the tile's rows, so the span's
+// table entry, its loss-table entries and the row-independent address parts are computed once per work item.
+// TWIDE (8192 x 19 000, tools/act_bench.py 5 TWIDE): 489 -> 388 us = 3.2 TB/s (0.41 of HBM; the 16-byte load did it:
+// 460 -> 386), with the loss 1113 -> 818 us (span-owner threads: 968 -> 818).  The SQ counters of the 386 us form: 195 M
+// wave-level VALU instructions per launch, VALU-active 207 M quad-cycles over 1024 SIMDs = 338 us - the kernel is
+// bound by its arithmetic, and ~60 % of that is the draw: Philox4x32-10's twenty quarter-rate 32 x 32 multiplies per
+// four elements and two logarithms per element (ln(-ln u)).  Rows per item 1 / 2 / 4 / 8 / 12 / 16 -> 628 / 470 / 388 /
+// 392 / 414 / 480 us; an 8-byte store for two-column spans +-0.
 constexpr int ACT_CHUNK = 256;
 
 template <bool LOSS>
@@ -333,7 +352,8 @@ __global__ __launch_bounds__(256) void activate_fwd_chunk_kernel(ActFwdArgs a, i
     const uint32_t rows = (uint32_t)min((int64_t)R, a.B - b0);
     const uint32_t nitem = rows * ns;
     const float inv_ns = 1.0f / (float)ns;
-    if ((uint64_t)R * w <= lds_floats && w < 32768u) {
+    const uint32_t ldw = w + 8u;                   // LDS row: 4 floats of padding in front, 4+ behind (see phase 1)
+    if ((uint64_t)R * ldw <= lds_floats && w < 32768u) {
       // ---- phase 1: one thread per (row, Philox block that touches the chunk's columns of the row)
       const uint32_t nqr = ((w + 3u) >> 2) + 1u, nit = rows * nqr;
       const float inv_nqr = 1.0f / (float)nqr;
@@ -343,80 +363,91 @@ __global__ __launch_bounds__(256) void activate_fwd_chunk_kernel(ActFwdArgs a, i
         const int c0 = (int)(j << 2) - (int)((uint32_t)fr & 3u);     // chunk-relative column of the block's first element
         if (c0 >= (int)w) continue;
         const float* __restrict__ xr = a.x + (b0 + r) * a.ldx + cA;
-        const float* __restrict__ er = a.en ? a.en + (b0 + r) * a.ld_en + cA : xr;
         float xv[4], ev[4];
+        // (one 16-byte load; only the matrix's first and last element have no neighbour to read over: see the narrow kernel)
+        if (((int)cA + c0 >= 0 || b0 + r > 0) && (cA + (uint32_t)(c0 + 3) < Dd || b0 + r + 1 < a.B)) {
+          const act_f4u q = *reinterpret_cast<const act_f4u*>(xr + c0);
+          xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+        } else {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          const int col = min(max(c0 + l, 0), (int)w - 1);
-          xv[l] = xr[col];
-          ev[l] = er[col];
+          for (int l = 0; l < 4; ++l) xv[l] = xr[min(max(c0 + l, 0), (int)w - 1)];
         }
-        if (!a.en) {
+        if (a.en) {
+          const float* __restrict__ er = a.en + (b0 + r) * a.ld_en + cA;
+#pragma unroll
+          for (int l = 0; l < 4; ++l) ev[l] = er[min(max(c0 + l, 0), (int)w - 1)];
+        } else {
           const DpcPhilox4 ph = dpc_philox(a.rng[0], a.rng[1], a.site, (fr >> 2) + j);
 #pragma unroll
           for (int l = 0; l < 4; ++l) ev[l] = dpc_exp1(ph.v[l]);
         }
-        float* tr = ts + r * w;
+        // all four values are stored: what hangs over the chunk's columns (c0 in -3 .. w-1) lands in the row's padding
+        float* tr = ts + r * ldw + 4u + c0;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          const int col = c0 + l;
-          if (col >= 0 && col < (int)w) tr[col] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
-        }
+        for (int l = 0; l < 4; ++l) tr[l] = (xv[l] - dpc_fast_ln(ev[l])) * a.inv_tau;
       }
       __syncthreads();
-      // ---- phase 2: one thread per (row, span of the chunk)
-      for (uint32_t it = threadIdx.x; it < nitem; it += 256) {
-        const uint32_t r = act_div(it, ns, inv_ns), s = it - r * ns;
+      // ---- phase 2: thread s holds span s of the chunk (ns <= 256 = the block) and walks the tile's rows: the span's
+      // table entry, its column and every row-independent address part are computed once; consecutive threads hold
+      // consecutive spans, so each row's stores are contiguous
+      if (threadIdx.x < ns) {
+        const uint32_t s = threadIdx.x;
         const int off = sp[3 * s], dim = sp[3 * s + 1], kind = sp[3 * s + 2];
-        const float* tr = ts + r * w + ((uint32_t)off - cA);
-        const float* __restrict__ xr = a.x + (b0 + r) * a.ldx + off;
-        float* __restrict__ yr = a.y + (b0 + r) * a.ldy + off;
-        float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + (b0 + r) * a.lddf + off : nullptr;
-        if (kind == 0) {
-          for (int j = 0; j < dim; ++j) {
-            yr[j] = dpc_fast_tanh(xr[j]);
-            if (LOSS && dr) dr[j] = 0.f;
-          }
-          continue;
-        }
-        if (dim <= 4) {
-          float t[4];
-          float mx = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t[j] = j < dim ? tr[j] : -INFINITY;
-            mx = fmaxf(mx, t[j]);
-          }
-          float sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t[j] = dpc_fast_exp(t[j] - mx);
-            sum += t[j];
-          }
-          const float inv = dpc_fast_rcp(sum);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < dim) yr[j] = t[j] * inv;
-        } else {
-          float mx = -INFINITY;
-          for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
-          float sum = 0.f;
-          for (int j = 0; j < dim; ++j) sum += dpc_fast_exp(tr[j] - mx);
-          const float inv = dpc_fast_rcp(sum);
-          for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_exp(tr[j] - mx) * inv;
-        }
+        int d = -1, cc = 0;
         if (LOSS) {
-          const int d = a.col2d[off];
-          const float m = d >= 0 ? (float)a.mask[(b0 + r) * a.ldm + d] : 0.f;
-          if (m != 0.f) {
-            const float* __restrict__ cr = a.cond + (b0 + r) * a.ldc + a.col2c[off];
+          d = a.col2d[off];
+          cc = a.col2c[off];
+        }
+        for (uint32_t r = 0; r < rows; ++r) {
+          const float* tr = ts + r * ldw + 4u + ((uint32_t)off - cA);
+          const float* __restrict__ xr = a.x + (b0 + r) * a.ldx + off;
+          float* __restrict__ yr = a.y + (b0 + r) * a.ldy + off;
+          float* __restrict__ dr = (LOSS && a.dfake) ? a.dfake + (b0 + r) * a.lddf + off : nullptr;
+          if (kind == 0) {
             for (int j = 0; j < dim; ++j) {
-              float gval;
-              acc += (double)act_loss_term(xr[j], cr[j], m, a.scale, gval);
-              if (dr) dr[j] = gval;
+              yr[j] = dpc_fast_tanh(xr[j]);
+              if (LOSS && dr) dr[j] = 0.f;
             }
-          } else if (dr) {
-            for (int j = 0; j < dim; ++j) dr[j] = 0.f;
+            continue;
+          }
+          if (dim <= 4) {
+            float t[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              t[j] = j < dim ? tr[j] : -INFINITY;
+              mx = fmaxf(mx, t[j]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              t[j] = dpc_fast_exp(t[j] - mx);
+              sum += t[j];
+            }
+            const float inv = dpc_fast_rcp(sum);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < dim) yr[j] = t[j] * inv;
+          } else {
+            float mx = -INFINITY;
+            for (int j = 0; j < dim; ++j) mx = fmaxf(mx, tr[j]);
+            float sum = 0.f;
+            for (int j = 0; j < dim; ++j) sum += dpc_fast_exp(tr[j] - mx);
+            const float inv = dpc_fast_rcp(sum);
+            for (int j = 0; j < dim; ++j) yr[j] = dpc_fast_exp(tr[j] - mx) * inv;
+          }
+          if (LOSS) {
+            const float m = d >= 0 ? (float)a.mask[(b0 + r) * a.ldm + d] : 0.f;
+            if (m != 0.f) {
+              const float* __restrict__ cr = a.cond + (b0 + r) * a.ldc + cc;
+              for (int j = 0; j < dim; ++j) {
+                float gval;
+                acc += (double)act_loss_term(xr[j], cr[j], m, a.scale, gval);
+                if (dr) dr[j] = gval;
+              }
+            } else if (dr) {
+              for (int j = 0; j < dim; ++j) dr[j] = 0.f;
+            }
           }
         }
       }
@@ -440,7 +471,7 @@ static int activate_fwd_impl(ActFwdArgs a, bool loss, int nd, int n_partials, in
   // (<= 40 KB of LDS) the smallest count whose phase-1 items - R rows x the nqr Philox blocks of a row - fill rounds
   // of 256 threads best, counting a grid beyond 2048 blocks (8 resident blocks per CU) as a quarter worse
   {
-    const int64_t ldT = (a.Dd + 3) / 4 * 4, nqr = (a.Dd + 3) / 4 + 1;
+    const int64_t ldT = (a.Dd + 3) / 4 * 4 + 8, nqr = (a.Dd + 3) / 4 + 1;
     auto lds_of = [&](int64_t R) {
       return ((size_t)R * ldT + 3 * (size_t)a.nspan + (loss ? 2 * (size_t)a.Dd + (size_t)R * nd : 0)) * 4;
     };
@@ -471,9 +502,9 @@ static int activate_fwd_impl(ActFwdArgs a, bool loss, int nd, int n_partials, in
   // still does not fit goes the direct way, in the kernel
   {
     const int64_t nchunk = dpc_cdiv((int64_t)a.nspan, ACT_CHUNK);
-    const int64_t guess = (a.Dd / nchunk) * 3 / 2 + 4;
+    const int64_t guess = (a.Dd / nchunk) * 3 / 2 + 12;      // (+ 8 floats of padding per LDS row)
     int64_t R = 12288 / guess;
-    R = R < 1 ? 1 : (R > 8 ? 8 : R);                   // (TWIDE, 12 steps of d_steps 10: R = 1 / 2 / 4 / 8 -> 91.4 / 89.5 / 88.6 / 88.4 ms)
+    R = R < 1 ? 1 : (R > 8 ? 8 : R);                   // (sweep: see the kernel's comment)
     if (R > a.B) R = a.B;
     const uint32_t lds_floats = (uint32_t)(R * guess < 12288 ? R * guess : 12288);
     a.R = (int)R;

@@ -1,5 +1,5 @@
 """The activation kernels alone at their in-step size (T1M schema, 8192 x 335): HIP events over back-to-back launches
-inside one captured graph (no host gaps).  usage: act_bench.py [reps]   (under rocprofv3 --pmc: the same launches)"""
+inside one captured graph (no host gaps).  usage: act_bench.py [reps [T1M|T10M|TWIDE]]   (under rocprofv3 --pmc: the same launches)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,8 @@ from dp_cgans_amd.engine import StepEngine
 from dp_cgans_amd.synthetic import build_encoded_table
 
 dev = torch.device('cuda:0')
-table, span = build_encoded_table('T1M', dev, n_rows=200000)
+name = sys.argv[2] if len(sys.argv) > 2 else 'T1M'
+table, span = build_encoded_table(name, dev, n_rows=200000 if name == 'T1M' else 20000)
 eng = StepEngine(span, 128, (256, 256), (256, 256), 8192, 8, dev, private=True, dp_mode='dpsgd', seed=0)
 eng.sampler = DataSampler(table, span, device=dev, seed=1)
 eng.train_step(1)
