@@ -47,7 +47,13 @@ struct ActFwdArgs {
 // Measured at T1M's 8192 x 335 (tools/act_bench.py, launches back to back in a graph): 20.7 -> 14.0 us, with the loss
 // 37 -> 23.5 us; then 11.9 / 22.1 us once the injected-draws pointer stopped aliasing x (`er = en ? en : x` made every
 // thread load its four raw values twice: 14.0 -> 12.3 us), the four clamped 4-byte loads became one 16-byte load
-// (-> 12.05) and the LDS stores lost their predicates (-> 11.9).  A plain copy of the same bytes takes 4.7 us.  With phases switched off one at a time: reading the
+// (-> 12.05) and the LDS stores lost their predicates (-> 11.9).  A plain copy of the same bytes takes 4.7 us.
+// What the loss adds to the 11.8 us (parts switched off one at a time, every index kept valid): the chosen spans'
+// terms 3.7 us, the zeros of the other spans' gradient 1.3 us, the fp64 block sum + partials 1.1 us, the mask tile's
+// loads 0.6 us, staging the two column tables and the rest of the LOSS template 3.2 us.  Tried for the 3.7 us and
+// not kept: a third phase with one wave per row and its lanes across the chosen span's categories (found by a
+// ballot over the row's spans) instead of the owner thread walking them alone: 22.1 -> 22.7 us - six rows on four
+// waves are two rounds of the same L2 round trip.  With phases switched off one at a time: reading the
 // rows into LDS alone 7.6 us, + coalesced stores 10.7 us (the load -> barrier -> store skeleton at ~20 KB in flight
 // per CU is latency-bound), Philox + logs 1.1 us, the span pass 5.5 us (12.7 us with the loss: one L2 round trip per
 // pass of its item loop).  Tried on top and not kept: raw rows and the tile's cond rows staged in LDS with span-owner
