@@ -558,6 +558,59 @@ def test_activation_and_cond_loss_in_one_pass_equal_the_two_kernels(ops):
         close([loss1], [float(loss0) * k], what='ce vs cond_loss kernel', rtol=1e-6)
 
 
+@pytest.mark.parametrize('Dd_target, B', [(6, 1), (13, 5), (335, 37), (9001, 3)])
+@pytest.mark.parametrize('shift, pad', [(0, 0), (1, 0), (2, 1), (3, 3)])
+def test_activation_forward_on_rows_at_any_alignment(ops, Dd_target, B, shift, pad):
+    """The kernels read a Philox block's four raw values with ONE 16-byte load at 4-byte alignment, and a block that
+    hangs over a row reads into the neighbouring row's storage (the matrix's first and last row clamp instead).  Rows
+    that start ``shift`` floats into a buffer, ``pad`` floats apart, with NaN everywhere around them, must give
+    exactly what an aligned copy gives: no neighbour value may reach a result, with and without the loss."""
+    from oracle import nets as onets
+    rng_np = np.random.default_rng(Dd_target + shift)
+    span, Dd = [], 0
+    while Dd < Dd_target:
+        k = min(int(rng_np.integers(1, 7)), Dd_target - Dd)
+        if rng_np.random() < 0.3 and Dd + 1 < Dd_target:
+            span.append((1, 0, 2)); Dd += 1
+            k = min(k, Dd_target - Dd)
+        span.append((k, 1, 1)); Dd += k
+    span_info = np.array(span, dtype=np.int32)
+    assert Dd == Dd_target
+    spans = span_table(span_info).to(dev())
+    x = torch.randn(B, Dd, generator=torch.Generator().manual_seed(4)).to(dev())
+    ld = Dd + pad
+    buf = torch.full((shift + B * ld + 8,), float('nan'), device=dev())
+    xv = buf[shift:shift + B * ld].view(B, ld)[:, :Dd]
+    xv.copy_(x)
+    assert xv.data_ptr() % 16 == (4 * shift) % 16
+    rng = ops.new_rng(23, dev())
+    y0, y1 = torch.empty(B, Dd, device=dev()), torch.empty(B, Dd, device=dev())
+    ops.apply_activate_fwd(x, y0, spans, rng=rng)
+    ops.apply_activate_fwd(xv, y1, spans, rng=rng)
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+    col2d, col2c = (t.to(dev()) for t in col_maps(span_info))
+    cols = onets.discrete_columns(span_info)
+    nd, C = len(cols), sum(k for _, _, k in cols)
+    g = torch.Generator().manual_seed(5)
+    cond = torch.zeros(B, C)
+    mask = torch.zeros(B, nd, dtype=torch.int32)
+    for b in range(B):
+        d = int(torch.randint(nd, (1,), generator=g))
+        mask[b, d] = 1
+        cond[b, cols[d][1] + int(torch.randint(cols[d][2], (1,), generator=g))] = 1.0
+    cond, mask = cond.to(dev()), mask.to(dev())
+    outs = []
+    for src in (x, xv):
+        part = torch.zeros(4096, dtype=torch.float64, device=dev())
+        d = torch.full((B, Dd), float('nan'), device=dev())
+        y = torch.empty(B, Dd, device=dev())
+        n = ops.activate_cond_loss_fwd(src, y, spans, cond, mask, col2d, col2c, nd, d, part, rng=rng)
+        outs.append((y, d, part[:n].sum()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], y0)
+    assert torch.isfinite(outs[1][1]).all() and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize('Dd_target', [9000, 20000, 40000])
 def test_activation_kernels_on_long_rows(ops, Dd_target):
     """Rows beyond the 8-row LDS tile: one row per tile (Dd 9000), one row in more than 48 KB of LDS
